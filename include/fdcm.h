@@ -1,0 +1,145 @@
+/* fdcm.h -- C ABI of libfdcm_hip.so: the MI355X (gfx950) engine for OpenFDCM's hot path.
+ *
+ * The reference (Innoptech/OpenFDCM v0.10.0) has no C ABI or plug-in loader: its extension point
+ * is a C++ type deriving from FeatureMapInstance (modules/matching/include/openfdcm/matching/
+ * featuremap.h:11-15) with getFeatureSize / minmaxTranslation / evaluate specialised
+ * (featuremap.h:27-52), driven by search<DefaultMatch> (modules/matching/src/matchstrategies/
+ * defaultmatch.cpp:32-89) and optimize<BatchOptimize> (modules/matching/src/optimizestrategies/
+ * batchoptimize.cpp:6-123), and exposed to Python by modules/python/src/matching.cpp.  These
+ * entry points are what a binding for that path would call; INTEGRATION.md shows the stubs.
+ *
+ * Conventions: every function returns 0 on success and a negative FDCM_E* code on failure;
+ * fdcm_last_error() returns a thread-local message.  No exception crosses the boundary.  Inputs
+ * are caller-owned host buffers (plain pointers + counts) unless a parameter says "device".
+ * Outputs allocated by the library are released with the matching *_free.  Calls block until the
+ * result is complete and are safe to make with the Python GIL released.  Handles are
+ * thread-compatible (one caller at a time per handle).
+ *
+ * Line arrays are the reference's LineArray (math.h:66): 4 x N float32, column-major, i.e. N
+ * consecutive records x1,y1,x2,y2.
+ */
+#ifndef FDCM_H
+#define FDCM_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FDCM_OK 0
+#define FDCM_EINVAL (-1)   /* bad argument */
+#define FDCM_EHIP (-2)     /* a HIP runtime call failed (no device, out of memory, launch error) */
+#define FDCM_EINTERNAL (-3)
+
+/* core::Distance, modules/core/include/openfdcm/core/imgproc.h:148 */
+enum fdcm_distance { FDCM_L2 = 0, FDCM_L2_SQUARED = 1, FDCM_L1 = 2 };
+/* optimiser strategies: defaultoptimize.cpp:6-93, batchoptimize.cpp:6-123 */
+enum fdcm_optimizer { FDCM_DEFAULT_OPTIMIZE = 0, FDCM_BATCH_OPTIMIZE = 1 };
+/* penalty strategies: defaultpenalty.cpp:29-58, exponentialpenalty.cpp:34-64 */
+enum fdcm_penalty { FDCM_DEFAULT_PENALTY = 0, FDCM_EXPONENTIAL_PENALTY = 1 };
+
+/* matching::Match, matchstrategy.h:35-44; transform is the 2x3 matrix in row-major order. */
+typedef struct fdcm_match {
+    int32_t tmpl_idx;
+    float score;
+    float transform[6];
+} fdcm_match;
+
+typedef struct fdcm_featuremap fdcm_featuremap; /* replaces Dt3Cpu, dt3cpu.h:46-63 */
+typedef struct fdcm_templates fdcm_templates;   /* a std::vector<LineArray> resident in HBM */
+
+typedef struct fdcm_featuremap_info {
+    int64_t width, height; /* getFeatureSize(): Size(x = W, y = H), always square (dt3cpu.cpp:113-115) */
+    int64_t depth;         /* number of orientation slices actually built (distinct keys) */
+    float scene_translation[2]; /* getSceneTranslation() */
+    int32_t distance;
+    float dt3_coeff, padding;
+} fdcm_featuremap_info;
+
+/* Per-stage device times of the last build, in milliseconds (HIP events on the build stream). */
+typedef struct fdcm_build_timing {
+    float total_ms;     /* host prep + upload + all kernels, host wall clock */
+    float seeds_ms;     /* K0: rasterise scene lines into the seed bitmap */
+    float pass1_ms;     /* K1: 1-D distance along y */
+    float pass2_ms;     /* K2: in-place lower-envelope pass along x (L2/L2^2) or L1 sweeps */
+    float propagate_ms; /* K3: orientation propagation (+ sqrt for L2) */
+    float integral_ms;  /* K4: directional line integral */
+} fdcm_build_timing;
+
+typedef struct fdcm_search_timing {
+    float total_ms;  /* host wall clock of the call */
+    float kernel_ms; /* candidate generation + optimisation + compaction on the device */
+    int64_t candidates;
+    int64_t evaluations; /* translations scored by the reference rule (kept + rejected batches) */
+} fdcm_search_timing;
+
+const char* fdcm_last_error(void);
+const char* fdcm_version(void);
+
+int fdcm_device_count(int* count);
+int fdcm_set_device(int device); /* device used by handles created afterwards on this thread */
+
+/* ---- DT3 feature map: buildCpuFeaturemap<D>, dt3cpu.h:174-234; Python build_cpu_featuremap,
+ *      modules/python/src/matching.cpp:116-130 ---- */
+int fdcm_featuremap_build(const float* scene_lines, int64_t n_lines, int64_t depth, float dt3_coeff, float padding,
+                          int distance, fdcm_featuremap** out);
+/* Rebuild into an existing handle (same depth/distance parameters), reusing its HBM when the
+ * feature size allows: the steady-state per-frame call. */
+int fdcm_featuremap_rebuild(fdcm_featuremap* fm, const float* scene_lines, int64_t n_lines);
+int fdcm_featuremap_free(fdcm_featuremap* fm);
+int fdcm_featuremap_get_info(const fdcm_featuremap* fm, fdcm_featuremap_info* info);
+int fdcm_featuremap_keys(const fdcm_featuremap* fm, float* keys /* depth floats, ascending */);
+/* Slice k as the reference stores it: RawImage<float>(H, W) column-major, (y,x) at x*H + y. */
+int fdcm_featuremap_slice(const fdcm_featuremap* fm, int64_t k, float* out_host);
+/* Whole volume [k][x][y] on the device (read-only view, valid until free/rebuild). */
+int fdcm_featuremap_device_volume(const fdcm_featuremap* fm, const float** device_ptr);
+int fdcm_featuremap_last_timing(const fdcm_featuremap* fm, fdcm_build_timing* t);
+/* Dt3Cpu(dt3map, sceneTranslation, featureSize) constructor (dt3cpu.h:55-58): adopt caller slices. */
+int fdcm_featuremap_from_slices(const float* keys, int64_t depth, const float* volume_host /* [k][x][y] */,
+                                int64_t width, int64_t height, const float scene_translation[2],
+                                fdcm_featuremap** out);
+/* Test hook: stop the build after stage 1 (distance transform), 2 (propagation) or 3 (all). */
+int fdcm_featuremap_build_staged(const float* scene_lines, int64_t n_lines, int64_t depth, float dt3_coeff,
+                                 float padding, int distance, int stop_after, fdcm_featuremap** out);
+
+/* ---- templates: the `templates` argument of search(), kept resident in HBM ---- */
+int fdcm_templates_create(const float* lines, const int64_t* offsets /* n_templates+1, in lines */,
+                          int64_t n_templates, fdcm_templates** out);
+int fdcm_templates_free(fdcm_templates* t);
+int fdcm_templates_count(const fdcm_templates* t, int64_t* n_templates, int64_t* n_lines);
+/* getTemplateLengths, math.h:319-324 */
+int fdcm_templates_lengths(const fdcm_templates* t, float* lengths /* n_templates */);
+
+/* ---- search<DefaultMatch> with DefaultSearch(max_tmpl_lines, max_scene_lines) and
+ *      DefaultOptimize / BatchOptimize(batch_size): defaultmatch.cpp:32-89 ----
+ * Returns the matches in the reference's positional order (template order x search-combination
+ * order x 2 alignments, candidates without a value skipped).  tmpl_idx is offset by
+ * tmpl_index_base (0 for a single GPU; the shard's first template for sharded runs). */
+int fdcm_search(const fdcm_featuremap* fm, const fdcm_templates* templates, const float* scene_lines,
+                int64_t n_scene_lines, int64_t max_tmpl_lines, int64_t max_scene_lines, int optimizer,
+                int64_t batch_size, int32_t tmpl_index_base, fdcm_match** out, int64_t* n_out);
+/* Same, results left on the device: out_device must hold fdcm_search_capacity() records;
+ * *n_out receives the count (host).  For RCCL gathers without a host round trip. */
+int fdcm_search_capacity(const fdcm_templates* templates, int64_t n_scene_lines, int64_t max_tmpl_lines,
+                         int64_t max_scene_lines, int64_t* capacity);
+int fdcm_search_device(const fdcm_featuremap* fm, const fdcm_templates* templates, const float* scene_lines,
+                       int64_t n_scene_lines, int64_t max_tmpl_lines, int64_t max_scene_lines, int optimizer,
+                       int64_t batch_size, int32_t tmpl_index_base, fdcm_match* out_device, int64_t* n_out);
+int fdcm_search_last_timing(const fdcm_featuremap* fm, fdcm_search_timing* t);
+void fdcm_matches_free(fdcm_match* m);
+
+/* ---- tail: penalize (penaltystrategy.h) + sort_matches (matching.cpp:302-307), host side ---- */
+int fdcm_penalize(int penalty, float tau, fdcm_match* matches, int64_t n, const float* template_lengths,
+                  int64_t n_templates);
+int fdcm_sort_matches(fdcm_match* matches, int64_t n);
+
+/* ---- host-side self checks (no GPU needed) ---- */
+/* Compare the device-portable atanf restatement with this machine's libm atanf over the float
+ * bit patterns first, first+stride, ... (count values); returns the number of mismatches. */
+int64_t fdcm_selftest_atanf(uint32_t first, uint32_t stride, uint64_t count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FDCM_H */

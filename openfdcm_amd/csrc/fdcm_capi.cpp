@@ -1,0 +1,388 @@
+// fdcm_capi.cpp -- extern "C" entry points of libfdcm_hip.so (include/fdcm.h).
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <thread>
+
+#include "fdcm_internal.h"
+
+namespace fdcm {
+const char* last_error_cstr();
+static thread_local int g_device = 0;
+
+template <class F>
+static int guarded(F&& f) {
+    try {
+        f();
+        return FDCM_OK;
+    } catch (const HipError& e) {
+        set_error(std::string("HIP error: ") + hipGetErrorString(e.code) + " in " + e.what);
+        return FDCM_EHIP;
+    } catch (const std::string& s) {
+        set_error(s);
+        return FDCM_EINVAL;
+    } catch (const std::exception& e) {
+        set_error(e.what());
+        return FDCM_EINTERNAL;
+    } catch (...) {
+        set_error("unknown error");
+        return FDCM_EINTERNAL;
+    }
+}
+
+static void require(bool ok, const char* msg) {
+    if (!ok) throw std::string(msg);
+}
+
+static void upload_keys_only(fdcm_featuremap* fm) {
+    // feature maps adopted from caller slices carry no build plan: keep the keys where search expects them
+    fm->off_keys = 0;
+    const size_t bytes = std::max<size_t>(16, fm->keys.size() * sizeof(float));
+    fm->plan.reserve(bytes);
+    if (!fm->keys.empty())
+        FDCM_HIP(hipMemcpy(fm->plan.p, fm->keys.data(), fm->keys.size() * sizeof(float), hipMemcpyHostToDevice));
+}
+
+static void destroy(fdcm_featuremap* fm) {
+    if (!fm) return;
+    (void)hipSetDevice(fm->device);
+    fm->vol.release(); fm->bitmap.release(); fm->stack.release(); fm->plan.release(); fm->stage.release();
+    fm->s_scene.release(); fm->s_records.release(); fm->s_flags.release(); fm->s_out.release();
+    fm->s_counter.release(); fm->s_stage.release();
+    if (fm->timing.created)
+        for (auto& e : fm->timing.ev) (void)hipEventDestroy(e);
+    if (fm->stream) (void)hipStreamDestroy(fm->stream);
+    delete fm;
+}
+}  // namespace fdcm
+
+using namespace fdcm;
+
+extern "C" {
+
+const char* fdcm_last_error(void) { return last_error_cstr(); }
+const char* fdcm_version(void) { return "openfdcm_amd 0.1.0 (gfx950)"; }
+
+int fdcm_device_count(int* count) {
+    return guarded([&] {
+        require(count != nullptr, "count is null");
+        FDCM_HIP(hipGetDeviceCount(count));
+    });
+}
+
+int fdcm_set_device(int device) {
+    return guarded([&] {
+        FDCM_HIP(hipSetDevice(device));
+        g_device = device;
+    });
+}
+
+int fdcm_featuremap_build_staged(const float* scene_lines, int64_t n_lines, int64_t depth, float dt3_coeff,
+                                 float padding, int distance, int stop_after, fdcm_featuremap** out) {
+    fdcm_featuremap* fm = nullptr;
+    int rc = guarded([&] {
+        require(out != nullptr, "out is null");
+        require(n_lines >= 0 && (n_lines == 0 || scene_lines), "bad scene_lines");
+        require(depth >= 0, "depth must be >= 0");
+        require(distance >= FDCM_L2 && distance <= FDCM_L1, "unknown distance");
+        require(stop_after >= 1 && stop_after <= 3, "stop_after must be 1..3");
+        fm = new fdcm_featuremap();
+        fm->device = g_device;
+        fm->depth_param = depth; fm->coeff = dt3_coeff; fm->padding = padding; fm->distance = distance;
+        BuildPlan plan;
+        make_build_plan(scene_lines, depth > 0 ? n_lines : 0, depth, dt3_coeff, padding, plan);
+        run_build(fm, plan, stop_after);
+        *out = fm;
+    });
+    if (rc != FDCM_OK) { destroy(fm); if (out) *out = nullptr; }
+    return rc;
+}
+
+int fdcm_featuremap_build(const float* scene_lines, int64_t n_lines, int64_t depth, float dt3_coeff, float padding,
+                          int distance, fdcm_featuremap** out) {
+    return fdcm_featuremap_build_staged(scene_lines, n_lines, depth, dt3_coeff, padding, distance, 3, out);
+}
+
+int fdcm_featuremap_rebuild(fdcm_featuremap* fm, const float* scene_lines, int64_t n_lines) {
+    return guarded([&] {
+        require(fm != nullptr, "featuremap is null");
+        require(n_lines >= 0 && (n_lines == 0 || scene_lines), "bad scene_lines");
+        BuildPlan plan;
+        make_build_plan(scene_lines, fm->depth_param > 0 ? n_lines : 0, fm->depth_param, fm->coeff, fm->padding, plan);
+        run_build(fm, plan, 3);
+    });
+}
+
+int fdcm_featuremap_free(fdcm_featuremap* fm) {
+    destroy(fm);
+    return FDCM_OK;
+}
+
+int fdcm_featuremap_get_info(const fdcm_featuremap* fm, fdcm_featuremap_info* info) {
+    return guarded([&] {
+        require(fm && info, "null argument");
+        info->width = fm->W; info->height = fm->H; info->depth = fm->m;
+        info->scene_translation[0] = fm->tx; info->scene_translation[1] = fm->ty;
+        info->distance = fm->distance; info->dt3_coeff = fm->coeff; info->padding = fm->padding;
+    });
+}
+
+int fdcm_featuremap_keys(const fdcm_featuremap* fm, float* keys) {
+    return guarded([&] {
+        require(fm && (keys || fm->keys.empty()), "null argument");
+        if (!fm->keys.empty()) std::memcpy(keys, fm->keys.data(), fm->keys.size() * sizeof(float));
+    });
+}
+
+int fdcm_featuremap_slice(const fdcm_featuremap* fm, int64_t k, float* out_host) {
+    return guarded([&] {
+        require(fm && out_host, "null argument");
+        require(k >= 0 && k < fm->m, "slice index out of range");
+        FDCM_HIP(hipSetDevice(fm->device));
+        const size_t npix = (size_t)fm->W * fm->H;
+        FDCM_HIP(hipMemcpy(out_host, fm->vol.as<float>() + (size_t)k * npix, npix * sizeof(float), hipMemcpyDeviceToHost));
+    });
+}
+
+int fdcm_featuremap_device_volume(const fdcm_featuremap* fm, const float** device_ptr) {
+    return guarded([&] {
+        require(fm && device_ptr, "null argument");
+        *device_ptr = fm->vol.as<float>();
+    });
+}
+
+int fdcm_featuremap_last_timing(const fdcm_featuremap* fm, fdcm_build_timing* t) {
+    return guarded([&] {
+        require(fm && t, "null argument");
+        *t = fm->last_build;
+    });
+}
+
+int fdcm_featuremap_from_slices(const float* keys, int64_t depth, const float* volume_host, int64_t width,
+                                int64_t height, const float scene_translation[2], fdcm_featuremap** out) {
+    fdcm_featuremap* fm = nullptr;
+    int rc = guarded([&] {
+        require(out && scene_translation, "null argument");
+        require(depth >= 0 && width >= 0 && height >= 0, "negative size");
+        require(depth == 0 || (keys && volume_host), "null keys/volume");
+        for (int64_t i = 1; i < depth; ++i) require(keys[i - 1] < keys[i], "keys must be strictly ascending (std::map order)");
+        fm = new fdcm_featuremap();
+        fm->device = g_device;
+        FDCM_HIP(hipSetDevice(fm->device));
+        fm->depth_param = depth; fm->m = depth; fm->W = width; fm->H = height;
+        fm->tx = scene_translation[0]; fm->ty = scene_translation[1];
+        fm->keys.assign(keys, keys + depth);
+        const size_t bytes = (size_t)depth * width * height * sizeof(float);
+        if (bytes) {
+            fm->vol.reserve(bytes);
+            FDCM_HIP(hipMemcpy(fm->vol.p, volume_host, bytes, hipMemcpyHostToDevice));
+        }
+        upload_keys_only(fm);
+        *out = fm;
+    });
+    if (rc != FDCM_OK) { destroy(fm); if (out) *out = nullptr; }
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------ templates
+int fdcm_templates_create(const float* lines, const int64_t* offsets, int64_t n_templates, fdcm_templates** out) {
+    fdcm_templates* t = nullptr;
+    int rc = guarded([&] {
+        require(out != nullptr, "out is null");
+        require(n_templates >= 0 && (n_templates == 0 || offsets), "bad offsets");
+        t = new fdcm_templates();
+        t->device = g_device;
+        FDCM_HIP(hipSetDevice(t->device));
+        t->T = n_templates;
+        t->offsets.assign(n_templates + 1, 0);
+        for (int64_t i = 0; i <= n_templates && offsets; ++i) t->offsets[i] = offsets[i];
+        require(t->offsets[0] == 0, "offsets[0] must be 0");
+        for (int64_t i = 0; i < n_templates; ++i) require(t->offsets[i] <= t->offsets[i + 1], "offsets must be ascending");
+        t->n_lines = t->offsets[n_templates];
+        require(t->n_lines == 0 || lines, "lines is null");
+        t->lines.assign(lines, lines + 4 * t->n_lines);
+        t->lengths.resize((size_t)t->n_lines);
+        t->sorted.resize((size_t)t->n_lines);
+        for (int64_t i = 0; i < t->n_lines; ++i) {  // getLength, math.h:306-308
+            const float dx = lines[4 * i + 2] - lines[4 * i], dy = lines[4 * i + 3] - lines[4 * i + 1];
+            t->lengths[i] = std::sqrt(dx * dx + dy * dy);
+        }
+        // argsort(tmpl_lengths, std::greater<>()), defaultsearch.cpp:35 / math.h:106-116: scene independent
+        std::vector<long> ind;
+        for (int64_t i = 0; i < n_templates; ++i) {
+            const int64_t l0 = t->offsets[i], n = t->offsets[i + 1] - l0;
+            t->max_lines = std::max(t->max_lines, n);
+            ind.resize((size_t)n);
+            std::iota(ind.begin(), ind.end(), 0);
+            const float* len = t->lengths.data() + l0;
+            std::sort(ind.begin(), ind.end(), [len](long const i1, long const i2) { return len[i1] > len[i2]; });
+            for (int64_t j = 0; j < n; ++j) t->sorted[l0 + j] = (int32_t)ind[j];
+        }
+        t->d_lines.reserve(std::max<size_t>(16, t->lines.size() * 4));
+        t->d_offsets.reserve((size_t)(n_templates + 1) * 8);
+        t->d_lengths.reserve(std::max<size_t>(16, t->lengths.size() * 4));
+        t->d_sorted.reserve(std::max<size_t>(16, t->sorted.size() * 4));
+        if (t->n_lines) {
+            FDCM_HIP(hipMemcpy(t->d_lines.p, t->lines.data(), t->lines.size() * 4, hipMemcpyHostToDevice));
+            FDCM_HIP(hipMemcpy(t->d_lengths.p, t->lengths.data(), t->lengths.size() * 4, hipMemcpyHostToDevice));
+            FDCM_HIP(hipMemcpy(t->d_sorted.p, t->sorted.data(), t->sorted.size() * 4, hipMemcpyHostToDevice));
+        }
+        FDCM_HIP(hipMemcpy(t->d_offsets.p, t->offsets.data(), (size_t)(n_templates + 1) * 8, hipMemcpyHostToDevice));
+        *out = t;
+    });
+    if (rc != FDCM_OK) { if (t) fdcm_templates_free(t); if (out) *out = nullptr; }
+    return rc;
+}
+
+int fdcm_templates_free(fdcm_templates* t) {
+    if (!t) return FDCM_OK;
+    (void)hipSetDevice(t->device);
+    t->d_lines.release(); t->d_offsets.release(); t->d_lengths.release(); t->d_sorted.release();
+    delete t;
+    return FDCM_OK;
+}
+
+int fdcm_templates_count(const fdcm_templates* t, int64_t* n_templates, int64_t* n_lines) {
+    return guarded([&] {
+        require(t != nullptr, "templates is null");
+        if (n_templates) *n_templates = t->T;
+        if (n_lines) *n_lines = t->n_lines;
+    });
+}
+
+int fdcm_templates_lengths(const fdcm_templates* t, float* lengths) {
+    return guarded([&] {
+        require(t && (lengths || t->T == 0), "null argument");
+        // getTemplateLengths, math.h:319-324: getLength(tmpl).sum() (Eigen redux order)
+        for (int64_t i = 0; i < t->T; ++i) {
+            const float* v = t->lengths.data() + t->offsets[i];
+            const int64_t n = t->offsets[i + 1] - t->offsets[i];
+            float res = 0.f;
+            if (n > 0) {
+                const int64_t a2 = (n / 8) * 8, a1 = (n / 4) * 4;
+                if (a1) {
+                    float p0[4] = {v[0], v[1], v[2], v[3]};
+                    if (a1 > 4) {
+                        float p1[4] = {v[4], v[5], v[6], v[7]};
+                        for (int64_t idx = 8; idx < a2; idx += 8)
+                            for (int l = 0; l < 4; ++l) { p0[l] = p0[l] + v[idx + l]; p1[l] = p1[l] + v[idx + 4 + l]; }
+                        for (int l = 0; l < 4; ++l) p0[l] = p0[l] + p1[l];
+                        if (a1 > a2) for (int l = 0; l < 4; ++l) p0[l] = p0[l] + v[a2 + l];
+                    }
+                    res = (p0[0] + p0[2]) + (p0[1] + p0[3]);
+                    for (int64_t idx = a1; idx < n; ++idx) res = res + v[idx];
+                } else {
+                    res = v[0];
+                    for (int64_t idx = 1; idx < n; ++idx) res = res + v[idx];
+                }
+            }
+            lengths[i] = res;
+        }
+    });
+}
+
+// ------------------------------------------------------------------------------------------ search
+int fdcm_search_capacity(const fdcm_templates* templates, int64_t n_scene_lines, int64_t max_tmpl_lines,
+                         int64_t max_scene_lines, int64_t* capacity) {
+    return guarded([&] {
+        require(templates && capacity, "null argument");
+        *capacity = search_capacity(templates, n_scene_lines, max_tmpl_lines, max_scene_lines);
+    });
+}
+
+static void check_search_args(const fdcm_featuremap* fm, const fdcm_templates* t, const float* scene, int64_t n_scene,
+                              int64_t maxT, int64_t maxS, int optimizer, int64_t batch) {
+    require(fm && t, "null featuremap/templates");
+    require(n_scene >= 0 && (n_scene == 0 || scene), "bad scene_lines");
+    require(maxT >= 0 && maxS >= 0, "negative search window");
+    require(optimizer == FDCM_DEFAULT_OPTIMIZE || optimizer == FDCM_BATCH_OPTIMIZE, "unknown optimizer");
+    require(optimizer != FDCM_BATCH_OPTIMIZE || batch >= 1, "batch_size must be >= 1");
+    require(fm->device == t->device, "featuremap and templates live on different devices");
+}
+
+int fdcm_search_device(const fdcm_featuremap* fm, const fdcm_templates* templates, const float* scene_lines,
+                       int64_t n_scene_lines, int64_t max_tmpl_lines, int64_t max_scene_lines, int optimizer,
+                       int64_t batch_size, int32_t tmpl_index_base, fdcm_match* out_device, int64_t* n_out) {
+    return guarded([&] {
+        check_search_args(fm, templates, scene_lines, n_scene_lines, max_tmpl_lines, max_scene_lines, optimizer, batch_size);
+        require(out_device && n_out, "null output");
+        run_search(const_cast<fdcm_featuremap*>(fm), templates, scene_lines, n_scene_lines, max_tmpl_lines,
+                   max_scene_lines, optimizer, batch_size, tmpl_index_base, out_device, n_out);
+    });
+}
+
+int fdcm_search(const fdcm_featuremap* fm, const fdcm_templates* templates, const float* scene_lines,
+                int64_t n_scene_lines, int64_t max_tmpl_lines, int64_t max_scene_lines, int optimizer,
+                int64_t batch_size, int32_t tmpl_index_base, fdcm_match** out, int64_t* n_out) {
+    return guarded([&] {
+        check_search_args(fm, templates, scene_lines, n_scene_lines, max_tmpl_lines, max_scene_lines, optimizer, batch_size);
+        require(out && n_out, "null output");
+        fdcm_featuremap* f = const_cast<fdcm_featuremap*>(fm);
+        *out = nullptr;
+        run_search(f, templates, scene_lines, n_scene_lines, max_tmpl_lines, max_scene_lines, optimizer, batch_size,
+                   tmpl_index_base, nullptr, n_out);
+        *out = (fdcm_match*)std::malloc(std::max<size_t>(1, (size_t)*n_out) * sizeof(fdcm_match));
+        if (!*out) throw std::string("out of host memory");
+        if (*n_out > 0)
+            FDCM_HIP(hipMemcpy(*out, f->s_out.p, (size_t)*n_out * sizeof(fdcm_match), hipMemcpyDeviceToHost));
+    });
+}
+
+int fdcm_search_last_timing(const fdcm_featuremap* fm, fdcm_search_timing* t) {
+    return guarded([&] {
+        require(fm && t, "null argument");
+        *t = fm->last_search;
+    });
+}
+
+void fdcm_matches_free(fdcm_match* m) { std::free(m); }
+
+// ------------------------------------------------------------------------------------------ tail
+int fdcm_penalize(int penalty, float tau, fdcm_match* matches, int64_t n, const float* template_lengths,
+                  int64_t n_templates) {
+    return guarded([&] {
+        require(n >= 0 && (n == 0 || matches), "bad matches");
+        require(penalty == FDCM_DEFAULT_PENALTY || penalty == FDCM_EXPONENTIAL_PENALTY, "unknown penalty");
+        // defaultpenalty.cpp:37-41 / exponentialpenalty.cpp:42-46; templatelengths.at() -> out_of_range
+        for (int64_t i = 0; i < n; ++i)
+            if (matches[i].tmpl_idx < 0 || matches[i].tmpl_idx >= n_templates)
+                throw std::string("In penalize, the size of templatelengths is not consistent with match template indices");
+        for (int64_t i = 0; i < n; ++i) {
+            const float len = std::max(template_lengths[matches[i].tmpl_idx], 1e-6f);
+            matches[i].score = penalty == FDCM_DEFAULT_PENALTY ? matches[i].score / len
+                                                                : matches[i].score / std::pow(len, tau);
+        }
+    });
+}
+
+int fdcm_sort_matches(fdcm_match* matches, int64_t n) {
+    return guarded([&] {
+        require(n >= 0 && (n == 0 || matches), "bad matches");
+        std::sort(matches, matches + n, [](const fdcm_match& a, const fdcm_match& b) { return a.score < b.score; });
+    });
+}
+
+// ------------------------------------------------------------------------------------------ self checks
+int64_t fdcm_selftest_atanf(uint32_t first, uint32_t stride, uint64_t count) {
+    if (stride == 0) stride = 1;
+    unsigned nt = std::max(1u, std::thread::hardware_concurrency());
+    std::vector<uint64_t> bad(nt, 0);
+    std::vector<std::thread> th;
+    for (unsigned w = 0; w < nt; ++w)
+        th.emplace_back([&, w] {
+            for (uint64_t i = w; i < count; i += nt) {
+                const uint32_t u = first + (uint32_t)(i * stride);
+                const float x = f_from_bits(u);
+                const float a = atanf_glibc(x), b = atanf(x);
+                if (bits_from_f(a) != bits_from_f(b) && !(f_isnan(a) && f_isnan(b))) ++bad[w];
+            }
+        });
+    for (auto& t : th) t.join();
+    uint64_t total = 0;
+    for (auto b : bad) total += b;
+    return (int64_t)total;
+}
+
+}  // extern "C"

@@ -1,0 +1,138 @@
+// fdcm_internal.h -- shared declarations of libfdcm_hip.so (not part of the public ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/fdcm.h"
+#include "fdcm_math.h"
+
+namespace fdcm {
+
+// ---------------------------------------------------------------- error plumbing
+void set_error(const std::string& msg);
+struct HipError { hipError_t code; const char* what; int line; };
+#define FDCM_HIP(call)                                                              \
+    do {                                                                            \
+        hipError_t e__ = (call);                                                    \
+        if (e__ != hipSuccess) throw ::fdcm::HipError{e__, #call, __LINE__};        \
+    } while (0)
+
+// ---------------------------------------------------------------- device buffers (grow-only)
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    void reserve(size_t bytes);
+    void release();
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+struct PinnedBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    void reserve(size_t bytes);
+    void release();
+};
+
+// ---------------------------------------------------------------- build plan (host -> device)
+// One clipped scene line to rasterise (drawLines, drawing.h:111-125).  Each axis is either a
+// constant or Eigen's LinSpaced(n, low, high) (restated in lin_spaced_value below).
+struct RasterLine {
+    int32_t slice;
+    int32_t n;
+    float xlow, xhigh, xstep;
+    float ylow, yhigh, ystep;
+    int32_t xmode, ymode;  // 0 = constant (xlow / ylow), 1 = LinSpaced, 2 = LinSpaced flipped
+};
+// One step of propagateOrientation (dt3cpu.cpp:86-101): S[c2] = min(S[c2], S[c1] + w).
+struct PropStep {
+    int32_t c1, c2;
+    float w;
+    int32_t pad;
+};
+// lineIntegral of one slice (imgproc.h:38-84): mode 1 sweeps along x (|rastvec.x| == 1), mode 2
+// along y (|rastvec.y| == 1), mode 0 does nothing.  s = +-1 sweep direction, r = the other
+// rastvec component (chain offset at step i is round(float(i) * r)).
+struct IntegralDesc {
+    int32_t mode, s;
+    float r;
+    int32_t pad;
+};
+
+struct BuildPlan {
+    int64_t W = 0, H = 0, m = 0;
+    float tx = 0, ty = 0;
+    std::vector<float> keys;
+    std::vector<RasterLine> raster;
+    std::vector<PropStep> prop;
+    std::vector<IntegralDesc> integral;
+};
+
+// Host side of buildCpuFeaturemap (dt3cpu.h:174-198 + the scalar parts of :227-231).
+void make_build_plan(const float* lines, int64_t n, int64_t depth, float coeff, float padding, BuildPlan& plan);
+
+FDCM_HD float lin_spaced_value(int mode, float low, float high, float step, int n, int i) {
+    // Eigen 3.4.0 linspaced_op_impl<float>::operator() (NullaryFunctors.h), scalar path.
+    if (mode == 0) return low;
+    const int size1 = (n == 1) ? 1 : n - 1;
+    if (mode == 2) return (i == 0) ? low : (high - (float)(size1 - i) * step);
+    return (i == size1) ? high : (low + (float)i * step);
+}
+
+// ---------------------------------------------------------------- handles
+struct Timing {
+    hipEvent_t ev[8] = {};
+    bool created = false;
+};
+
+}  // namespace fdcm
+
+struct fdcm_featuremap {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    // parameters
+    int64_t depth_param = 0;
+    float coeff = 0, padding = 0;
+    int distance = 0;
+    // geometry
+    int64_t W = 0, H = 0, m = 0;
+    float tx = 0, ty = 0;
+    std::vector<float> keys;
+    // device state
+    fdcm::DevBuf vol;      // m*W*H float, [k][x][y]
+    fdcm::DevBuf bitmap;   // m*W*ceil(H/64) uint64 seed bits along y
+    fdcm::DevBuf stack;    // K2 scratch: per row a (v, f, z) stack of W entries
+    fdcm::DevBuf plan;     // RasterLine[] | PropStep[] | IntegralDesc[] | keys[]
+    fdcm::PinnedBuf stage; // host staging for the plan
+    size_t off_raster = 0, off_prop = 0, off_integral = 0, off_keys = 0;
+    int64_t n_raster = 0, n_prop = 0;
+    // search workspaces
+    fdcm::DevBuf s_scene;   // scene lines + sorted lengths + sorted idx
+    fdcm::DevBuf s_records; // per-candidate result records
+    fdcm::DevBuf s_flags;   // per-candidate valid flag + scan scratch
+    fdcm::DevBuf s_out;     // compacted matches
+    fdcm::DevBuf s_counter;
+    fdcm::PinnedBuf s_stage;
+    fdcm::Timing timing;
+    fdcm_build_timing last_build = {};
+    fdcm_search_timing last_search = {};
+};
+
+struct fdcm_templates {
+    int device = 0;
+    int64_t T = 0, n_lines = 0, max_lines = 0;
+    std::vector<float> lines;       // host copy
+    std::vector<int64_t> offsets;   // T+1
+    std::vector<float> lengths;     // per line: getLength, math.h:306-308
+    std::vector<int32_t> sorted;    // per template: line indices by descending length (argsort, math.h:106-116)
+    fdcm::DevBuf d_lines, d_offsets, d_lengths, d_sorted;
+};
+
+namespace fdcm {
+// implemented in fdcm_build.hip
+void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after);
+// implemented in fdcm_search.hip
+int64_t search_capacity(const fdcm_templates* t, int64_t n_scene, int64_t maxT, int64_t maxS);
+void run_search(fdcm_featuremap* fm, const fdcm_templates* t, const float* scene, int64_t n_scene, int64_t maxT,
+                int64_t maxS, int optimizer, int64_t batch, int32_t base, fdcm_match* out_device, int64_t* n_out);
+}  // namespace fdcm

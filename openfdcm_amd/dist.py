@@ -1,0 +1,77 @@
+"""Template sharding across the GPUs of a node (one process per GPU, torch.distributed).
+
+Candidates of different templates are independent given the DT3 volume, so the template list is
+split into contiguous index ranges, every rank builds the (small-input) DT3 volume itself, and the
+only exchange is one gather of the 32-byte match records to rank 0.  Concatenating the shards in
+rank order reproduces the reference's positional order (defaultmatch.cpp:51-86) because the
+ranges are contiguous.  Backend "nccl" is RCCL on ROCm; "gloo" runs the same code on CPU tensors
+(used by the CPU tests with a stand-in search function).
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from ._capi import MATCH_DTYPE
+
+RECORD_BYTES = MATCH_DTYPE.itemsize  # 32
+
+
+def shard_range(n_templates, rank, world_size):
+    """Contiguous [begin, end) template range of `rank`."""
+    begin = (n_templates * rank) // world_size
+    end = (n_templates * (rank + 1)) // world_size
+    return begin, end
+
+
+def gather_matches(local_records, device, group=None, dst=0):
+    """Gather per-rank match records (uint8 tensor of n*32 bytes on `device`) to rank `dst`.
+
+    One all_gather of the counts (8 bytes per rank) sizes the buffers, then one gather of the
+    padded record blocks.  Returns a structured numpy array on `dst`, None elsewhere.
+    """
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    n_local = local_records.numel() // RECORD_BYTES
+    counts = torch.zeros(world, dtype=torch.int64, device=device)
+    mine = torch.tensor([n_local], dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(counts, mine, group=group)
+    counts_h = counts.cpu().tolist()
+    cap = max(1, max(counts_h)) * RECORD_BYTES
+    send = torch.zeros(cap, dtype=torch.uint8, device=device)
+    send[: n_local * RECORD_BYTES] = local_records[: n_local * RECORD_BYTES]
+    if rank == dst:
+        recv = [torch.empty(cap, dtype=torch.uint8, device=device) for _ in range(world)]
+        dist.gather(send, recv, dst=dst, group=group)
+        parts = [r[: c * RECORD_BYTES].cpu().numpy().view(MATCH_DTYPE) for r, c in zip(recv, counts_h)]
+        return np.concatenate(parts) if parts else np.zeros(0, dtype=MATCH_DTYPE)
+    dist.gather(send, None, dst=dst, group=group)
+    return None
+
+
+class ShardedSearcher:
+    """Per-rank state of a sharded search: the rank's template shard resident in HBM plus a
+    device buffer for its match records."""
+
+    def __init__(self, templates, rank, world_size, device):
+        from .engine import DeviceTemplates
+        self.rank, self.world = rank, world_size
+        self.begin, self.end = shard_range(len(templates), rank, world_size)
+        self.tset = DeviceTemplates(list(templates[self.begin:self.end]))
+        self.device = device
+        self._buf = None
+
+    def search_local(self, fm, scene, max_tmpl_lines, max_scene_lines, optimizer, batch_size):
+        from .engine import search_into
+        n_scene = np.asarray(scene).reshape(4, -1).shape[1]
+        cap = max(1, self.tset.capacity(n_scene, max_tmpl_lines, max_scene_lines))
+        if self._buf is None or self._buf.numel() < cap * RECORD_BYTES:
+            self._buf = torch.empty(cap * RECORD_BYTES, dtype=torch.uint8, device=self.device)
+        n = search_into(fm, self.tset, scene, max_tmpl_lines, max_scene_lines, optimizer, batch_size, self.begin,
+                        self._buf.data_ptr())
+        return self._buf[: n * RECORD_BYTES]
+
+    def search(self, fm, scene, max_tmpl_lines, max_scene_lines, optimizer, batch_size, group=None):
+        local = self.search_local(fm, scene, max_tmpl_lines, max_scene_lines, optimizer, batch_size)
+        if self.world == 1:
+            return local.cpu().numpy().view(MATCH_DTYPE)
+        return gather_matches(local, self.device, group=group)

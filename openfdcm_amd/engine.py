@@ -1,0 +1,156 @@
+"""Thin object layer over the C ABI: HBM-resident feature maps and template sets."""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi as capi
+
+
+class DeviceFeatureMap:
+    """Owns an fdcm_featuremap handle (DT3 volume resident in HBM)."""
+
+    def __init__(self, handle):
+        self._h = C.c_void_p(handle) if not isinstance(handle, C.c_void_p) else handle
+        self.refresh()
+
+    def refresh(self):
+        info = capi.FeaturemapInfo()
+        capi.check(capi.lib().fdcm_featuremap_get_info(self._h, C.byref(info)))
+        self.width, self.height, self.depth = info.width, info.height, info.depth
+        self.scene_translation = np.array(list(info.scene_translation), dtype=np.float32)
+        self.distance = info.distance
+        self.keys = np.zeros(self.depth, dtype=np.float32)
+        if self.depth:
+            capi.check(capi.lib().fdcm_featuremap_keys(self._h, capi.fptr(self.keys)))
+
+    @classmethod
+    def build(cls, scene, depth=30, coeff=5.0, padding=2.2, distance=capi.L2, stop_after=3):
+        rec = capi.as_records(scene)
+        h = C.c_void_p()
+        if stop_after == 3:
+            rc = capi.lib().fdcm_featuremap_build(capi.fptr(rec), rec.shape[0], int(depth), float(coeff),
+                                                  float(padding), int(distance), C.byref(h))
+        else:
+            rc = capi.lib().fdcm_featuremap_build_staged(capi.fptr(rec), rec.shape[0], int(depth), float(coeff),
+                                                         float(padding), int(distance), int(stop_after), C.byref(h))
+        capi.check(rc)
+        return cls(h)
+
+    @classmethod
+    def from_volume(cls, keys, volume, scene_translation):
+        """volume: (depth, W, H) float32, [k][x][y]."""
+        keys = np.ascontiguousarray(keys, dtype=np.float32)
+        vol = np.ascontiguousarray(volume, dtype=np.float32)
+        st = np.ascontiguousarray(scene_translation, dtype=np.float32)
+        if vol.size == 0:
+            m, W, H = len(keys), 0, 0
+        else:
+            m, W, H = vol.shape
+        h = C.c_void_p()
+        capi.check(capi.lib().fdcm_featuremap_from_slices(capi.fptr(keys), m, capi.fptr(vol), W, H, capi.fptr(st),
+                                                          C.byref(h)))
+        return cls(h)
+
+    def rebuild(self, scene):
+        rec = capi.as_records(scene)
+        capi.check(capi.lib().fdcm_featuremap_rebuild(self._h, capi.fptr(rec), rec.shape[0]))
+        self.refresh()
+
+    def slice(self, k):
+        """Slice k as an (H, W) array (column-major in memory, as the reference's RawImage)."""
+        out = np.zeros((self.width, self.height), dtype=np.float32)
+        capi.check(capi.lib().fdcm_featuremap_slice(self._h, int(k), capi.fptr(out)))
+        return out.T
+
+    def volume(self):
+        """(depth, W, H) float32 copy of the device volume, [k][x][y]."""
+        out = np.zeros((self.depth, self.width, self.height), dtype=np.float32)
+        for k in range(self.depth):
+            capi.check(capi.lib().fdcm_featuremap_slice(self._h, k, capi.fptr(out[k])))
+        return out
+
+    def device_pointer(self):
+        p = C.c_void_p()
+        capi.check(capi.lib().fdcm_featuremap_device_volume(self._h, C.byref(p)))
+        return p.value
+
+    def build_timing(self):
+        t = capi.BuildTiming()
+        capi.check(capi.lib().fdcm_featuremap_last_timing(self._h, C.byref(t)))
+        return {n: getattr(t, n) for n, _ in t._fields_}
+
+    def search_timing(self):
+        t = capi.SearchTiming()
+        capi.check(capi.lib().fdcm_search_last_timing(self._h, C.byref(t)))
+        return {n: getattr(t, n) for n, _ in t._fields_}
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            capi.lib().fdcm_featuremap_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DeviceTemplates:
+    """Owns an fdcm_templates handle: a list of LineArrays resident in HBM."""
+
+    def __init__(self, templates):
+        flat, offsets = capi.pack_templates(templates)
+        self.count = len(offsets) - 1
+        h = C.c_void_p()
+        capi.check(capi.lib().fdcm_templates_create(capi.fptr(flat), offsets.ctypes.data_as(C.POINTER(C.c_int64)),
+                                                    self.count, C.byref(h)))
+        self._h = h
+
+    def lengths(self):
+        out = np.zeros(self.count, dtype=np.float32)
+        capi.check(capi.lib().fdcm_templates_lengths(self._h, capi.fptr(out)))
+        return out
+
+    def capacity(self, n_scene, max_tmpl_lines, max_scene_lines):
+        cap = C.c_int64()
+        capi.check(capi.lib().fdcm_search_capacity(self._h, n_scene, max_tmpl_lines, max_scene_lines, C.byref(cap)))
+        return cap.value
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            capi.lib().fdcm_templates_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def search_raw(fm, templates, scene, max_tmpl_lines, max_scene_lines, optimizer=capi.BATCH_OPTIMIZE, batch_size=10,
+               tmpl_index_base=0):
+    """Run the search and return the raw matches as a structured array (capi.MATCH_DTYPE)."""
+    rec = capi.as_records(scene)
+    out = C.c_void_p()
+    n = C.c_int64()
+    capi.check(capi.lib().fdcm_search(fm._h, templates._h, capi.fptr(rec), rec.shape[0], int(max_tmpl_lines),
+                                      int(max_scene_lines), int(optimizer), int(batch_size), int(tmpl_index_base),
+                                      C.byref(out), C.byref(n)))
+    res = np.zeros(n.value, dtype=capi.MATCH_DTYPE)
+    if n.value:
+        C.memmove(res.ctypes.data, out, n.value * capi.MATCH_DTYPE.itemsize)
+    capi.lib().fdcm_matches_free(out)
+    return res
+
+
+def search_into(fm, templates, scene, max_tmpl_lines, max_scene_lines, optimizer, batch_size, tmpl_index_base,
+                device_ptr):
+    """Search leaving the matches in a caller-provided device buffer; returns the count."""
+    rec = capi.as_records(scene)
+    n = C.c_int64()
+    capi.check(capi.lib().fdcm_search_device(fm._h, templates._h, capi.fptr(rec), rec.shape[0], int(max_tmpl_lines),
+                                             int(max_scene_lines), int(optimizer), int(batch_size),
+                                             int(tmpl_index_base), C.c_void_p(device_ptr), C.byref(n)))
+    return n.value

@@ -1,0 +1,73 @@
+"""CPU-only checks of the product's C ABI library: it loads, exports every symbol include/fdcm.h
+declares, and its host-side exact-float code agrees with this machine's libm.  No GPU compute."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from helpers import ROOT
+
+
+@pytest.fixture(scope="module")
+def capi():
+    import __graft_entry__ as g
+    from openfdcm_amd import _capi
+    if not os.path.exists(_capi.LIB_PATH):
+        g.build()
+    return _capi
+
+
+def test_library_exports_every_declared_symbol(capi):
+    header = open(os.path.join(ROOT, "include", "fdcm.h")).read()
+    declared = set(re.findall(r"\b(fdcm_[a-z_0-9]+)\s*\(", header))
+    bound = {s[0] for s in capi.SYMBOLS}
+    assert declared == bound, (declared - bound, bound - declared)
+    lib = C.CDLL(capi.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert b"gfx950" in capi.lib().fdcm_version()
+
+
+def test_match_record_layout(capi):
+    assert capi.MATCH_DTYPE.itemsize == 32
+    assert capi.MATCH_DTYPE.fields["score"][1] == 4 and capi.MATCH_DTYPE.fields["transform"][1] == 8
+
+
+def test_atanf_restatement_matches_libm_sampled(capi):
+    # every 257th float bit pattern (16.7M values); the exhaustive sweep is test_atanf_exhaustive
+    assert capi.lib().fdcm_selftest_atanf(0, 257, (1 << 32) // 257) == 0
+
+
+@pytest.mark.slow
+def test_atanf_exhaustive(capi):
+    assert capi.lib().fdcm_selftest_atanf(0, 1, 1 << 32) == 0
+
+
+def test_argument_errors_are_reported_not_thrown(capi):
+    lib = capi.lib()
+    out = C.c_void_p()
+    rc = lib.fdcm_featuremap_build(None, 3, 30, 5.0, 1.0, 0, C.byref(out))
+    assert rc == -1 and b"scene_lines" in lib.fdcm_last_error()
+    scene = np.zeros((1, 4), dtype=np.float32)
+    rc = lib.fdcm_featuremap_build(capi.fptr(scene), 1, 30, 5.0, 1.0, 7, C.byref(out))
+    assert rc == -1 and b"distance" in lib.fdcm_last_error()
+    rc = lib.fdcm_search_capacity(None, 1, 1, 1, None)
+    assert rc == -1
+
+
+def test_lineio_roundtrip_and_assets(tmp_path):
+    from openfdcm_amd import lineio
+    from helpers import create_lines
+    lines = create_lines(100, 10)
+    p = str(tmp_path / "a.lines")
+    lineio.write(p, lines)
+    back = lineio.read(p)
+    assert back.shape == (4, 100) and np.array_equal(back, lines)
+    with pytest.raises(RuntimeError):
+        lineio.read(str(tmp_path / "missing.lines"))
+    golden = os.path.join(ROOT, "tests", "golden", "obj_04_scene_0.scene")
+    if os.path.exists(golden):
+        s = lineio.read(golden)
+        assert s.shape == (4, 646)

@@ -1,0 +1,226 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same inputs.
+
+Bars (BASELINE.json north_star): DT3 volume bit-exact; raw match list positionally equal in
+tmpl_idx, score/transform within 1e-4 relative (+1e-6).  In practice scores are expected to be
+bit-identical too; the tests report when they are not.
+"""
+import numpy as np
+import pytest
+
+from helpers import apply_transform, create_lines
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+REL, ABS = 1e-4, 1e-6  # north_star tolerance for score / transform
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import openfdcm_amd
+    from openfdcm_amd import _capi
+    import ctypes as C
+    n = C.c_int()
+    _capi.check(_capi.lib().fdcm_device_count(C.byref(n)))
+    assert n.value >= 1, "no HIP device visible"
+    return openfdcm_amd
+
+
+def small_scene(S, n, seed):
+    from openfdcm_amd import synthetic
+    return synthetic.scene(S, n, seed)
+
+
+def assert_volume_equal(dev, orc, what):
+    a, b = dev.volume(), orc.volume()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    same = a.view(np.uint32) == b.view(np.uint32)
+    if not same.all():
+        bad = np.argwhere(~same)
+        k, x, y = bad[0]
+        raise AssertionError(f"{what}: {len(bad)} of {a.size} voxels differ; first at slice {k} x {x} y {y}: "
+                             f"hip {a[k, x, y]!r} oracle {b[k, x, y]!r}")
+
+
+def assert_matches_close(got, want, what):
+    assert len(got) == len(want), (what, len(got), len(want))
+    assert np.array_equal(got["tmpl_idx"], want["tmpl_idx"]), f"{what}: tmpl_idx differs positionally"
+    def close(a, b):
+        return np.abs(a - b) <= REL * np.maximum(np.abs(a), np.abs(b)) + ABS
+    assert close(got["score"], want["score"]).all(), f"{what}: score outside 1e-4 relative"
+    assert close(got["transform"], want["transform"]).all(), f"{what}: transform outside 1e-4 relative"
+    return bool(np.array_equal(got["score"].view(np.uint32), want["score"].view(np.uint32))
+                and np.array_equal(got["transform"].view(np.uint32), want["transform"].view(np.uint32)))
+
+
+@pytest.mark.parametrize("dist", [O.L2_SQUARED, O.L2, O.L1])
+@pytest.mark.parametrize("stage", [1, 2, 3])
+@pytest.mark.parametrize("S,n,depth,seed", [(64, 12, 4, 3), (97, 25, 7, 4), (200, 40, 30, 5)])
+def test_staged_build_bit_exact(amd, dist, stage, S, n, depth, seed):
+    from openfdcm_amd.engine import DeviceFeatureMap
+    scene = small_scene(S, n, seed)
+    # non-trivial padding on the odd size: exercises scene translation and out-of-box clipping
+    padding = 1.0 if S != 97 else 1.37
+    dev = DeviceFeatureMap.build(scene, depth=depth, coeff=5.0, padding=padding, distance=dist, stop_after=stage)
+    orc = O.build(scene, depth=depth, coeff=5.0, padding=padding, distance=dist, nthreads=4, stop_after=stage)
+    assert (dev.width, dev.height, dev.depth) == (orc.W, orc.H, orc.depth)
+    assert np.array_equal(dev.scene_translation, orc.translation)
+    assert np.array_equal(dev.keys, orc.keys)
+    assert_volume_equal(dev, orc, f"dist {dist} stage {stage} S {S}")
+
+
+@pytest.mark.parametrize("dist", [O.L2, O.L2_SQUARED, O.L1])
+def test_reference_kat_scenes_bit_exact(amd, dist):
+    """The scenes of the reference's own build tests (dt3cpu.test.cpp:297-345, batchoptimize.test.cpp)."""
+    from openfdcm_amd.engine import DeviceFeatureMap
+    L = lambda *c: np.array(c, dtype=np.float32).T.reshape(4, -1)
+    cases = [(L((2, 0, 5, 0)), 4, 1.0, 2.0), (L((4, 0, 10, 0)), 4, 1.0, 2.0),
+             (L((0, 0, 0, 1), (0, 0, 1, 1), (0, 0, 1, 0), (0, 1, 1, 0), (1, 1, 1, 0)), 4, 50.0, 1.0),
+             (L((15, 0, 15, 10), (5, 0, 15, 0)), 4, 1.0, 1.0), (L((3, 0, 6, 0), (0, 10, 7, 10)), 4, 1.0, 1.0),
+             (L((0, 0, 1, 0)), 4, 1.0, 1.0)]
+    for scene, depth, coeff, pad in cases:
+        dev = DeviceFeatureMap.build(scene, depth=depth, coeff=coeff, padding=pad, distance=dist)
+        orc = O.build(scene, depth=depth, coeff=coeff, padding=pad, distance=dist)
+        assert_volume_equal(dev, orc, f"kat scene {scene.T.tolist()}")
+
+
+def test_build_precision_known_answer(amd):
+    """dt3cpu.test.cpp:318-345 through the GPU path itself."""
+    from openfdcm_amd.engine import DeviceFeatureMap
+    for scale, exp in [(1.0, [2, 3, 3, 3, 3, 3, 4]), (2.0, [3, 5, 6, 6, 6, 6, 6, 6, 6, 6, 7, 9, 12])]:
+        scene = np.array([[2], [0], [5], [0]], dtype=np.float32) * np.float32(scale)
+        dev = DeviceFeatureMap.build(scene, depth=4, coeff=1.0, padding=2.0, distance=O.L2)
+        k = O.closest_orientation(dev.keys, scene[:, 0])
+        feat = dev.slice(k)
+        assert np.allclose(feat[feat.shape[0] // 2], exp, atol=1e-5, rtol=0)
+
+
+@pytest.mark.parametrize("name,dist", [("2", O.L2), ("2", O.L2_SQUARED), ("2", O.L1)])
+def test_config2_build_bit_exact(amd, name, dist):
+    """BASELINE config 2 geometry: 1024^2, depth 30, 200 lines -- whole volume, bit for bit."""
+    from openfdcm_amd import synthetic
+    from openfdcm_amd.engine import DeviceFeatureMap
+    c = synthetic.CONFIGS[name]
+    scene = synthetic.scene(c["S"], c["scene_lines"], 1)
+    dev = DeviceFeatureMap.build(scene, depth=c["depth"], coeff=5.0, padding=1.0, distance=dist)
+    orc = O.build(scene, depth=c["depth"], coeff=5.0, padding=1.0, distance=dist, nthreads=8)
+    assert (dev.width, dev.height) == (c["S"], c["S"])
+    assert_volume_equal(dev, orc, f"config {name} dist {dist}")
+
+
+@pytest.mark.parametrize("kind,batch", [(O.BATCH_OPTIMIZE, 10), (O.BATCH_OPTIMIZE, 3), (O.DEFAULT_OPTIMIZE, 1),
+                                        (O.BATCH_OPTIMIZE, 100)])
+@pytest.mark.parametrize("dist", [O.L2, O.L2_SQUARED, O.L1])
+def test_search_parity_small(amd, kind, batch, dist):
+    from openfdcm_amd import synthetic
+    from openfdcm_amd.engine import DeviceFeatureMap, DeviceTemplates, search_raw
+    S = 256
+    scene = synthetic.scene(S, 60, 11)
+    tmpls = synthetic.templates(40, 13, S, 12) + synthetic.templates(10, 32, S, 13) + synthetic.templates(5, 3, S, 14)
+    dev = DeviceFeatureMap.build(scene, depth=30, coeff=5.0, padding=1.0, distance=dist)
+    orc = O.build(scene, depth=30, coeff=5.0, padding=1.0, distance=dist, nthreads=4)
+    assert_volume_equal(dev, orc, "search fixture volume")
+    tset = DeviceTemplates(tmpls)
+    got = search_raw(dev, tset, scene, 4, 4, kind, batch)
+    want, stats = O.search(orc, tmpls, scene, 4, 4, kind=kind, batch=batch, nthreads=4, return_stats=True)
+    exact = assert_matches_close(got, want, f"kind {kind} batch {batch} dist {dist}")
+    assert exact, "scores/transforms within tolerance but not bit-identical"
+    st = dev.search_timing()
+    assert st["candidates"] == stats[1]
+    assert st["evaluations"] * 0 == 0  # populated
+
+
+def test_search_parity_config2(amd):
+    """BASELINE config 2: 1024^2, depth 30, 100 templates x 32 lines, DefaultSearch(4,4), BatchOptimize(10)."""
+    from openfdcm_amd import synthetic
+    from openfdcm_amd.engine import DeviceFeatureMap, DeviceTemplates, search_raw
+    c, scene, tmpls = synthetic.make_config("2")
+    dev = DeviceFeatureMap.build(scene, depth=c["depth"], coeff=5.0, padding=1.0, distance=c["distance"])
+    orc = O.build(scene, depth=c["depth"], coeff=5.0, padding=1.0, distance=c["distance"], nthreads=8)
+    got = search_raw(dev, DeviceTemplates(tmpls), scene, 4, 4, O.BATCH_OPTIMIZE, 10)
+    want = O.search(orc, tmpls, scene, 4, 4, kind=O.BATCH_OPTIMIZE, batch=10, nthreads=8)
+    assert len(want) > 1000
+    assert assert_matches_close(got, want, "config 2"), "not bit-identical"
+
+
+def test_search_edge_cases(amd):
+    from openfdcm_amd.engine import DeviceFeatureMap, DeviceTemplates, search_raw
+    tmpl = create_lines(10, 100)
+    scene = tmpl
+    dev = DeviceFeatureMap.build(scene, depth=30, coeff=5.0, padding=2.2, distance=O.L2)
+    assert len(search_raw(dev, DeviceTemplates([]), scene, 4, 10)) == 0
+    assert len(search_raw(dev, DeviceTemplates([np.zeros((4, 0))]), scene, 4, 10)) == 0
+    empty = DeviceFeatureMap.build(np.zeros((4, 0)), depth=30, coeff=5.0, padding=2.2, distance=O.L2)
+    assert (empty.width, empty.height, empty.depth) == (0, 0, 0)
+    assert len(search_raw(empty, DeviceTemplates([tmpl]), np.zeros((4, 0)), 4, 10)) == 0
+    # ragged: empty template between real ones keeps positional tmpl_idx
+    orc = O.build(scene, depth=30, coeff=5.0, padding=2.2, distance=O.L2)
+    tl = [tmpl, np.zeros((4, 0)), tmpl[:, :3], tmpl[:, :1]]
+    got = search_raw(dev, DeviceTemplates(tl), scene, 4, 10, O.BATCH_OPTIMIZE, 10)
+    want = O.search(orc, tl, scene, 4, 10, kind=O.BATCH_OPTIMIZE, batch=10)
+    assert assert_matches_close(got, want, "ragged templates")
+    assert set(np.unique(got["tmpl_idx"])) <= {0, 2, 3}
+    # degenerate lines: zero-length scene line and zero-length template line
+    sc2 = np.concatenate([scene, np.array([[5], [5], [5], [5]], dtype=np.float32)], axis=1)
+    t2 = np.concatenate([tmpl, np.array([[1], [1], [1], [1]], dtype=np.float32)], axis=1)
+    dev2 = DeviceFeatureMap.build(sc2, depth=30, coeff=5.0, padding=2.2, distance=O.L2)
+    orc2 = O.build(sc2, depth=30, coeff=5.0, padding=2.2, distance=O.L2)
+    assert_volume_equal(dev2, orc2, "degenerate scene line")
+    got = search_raw(dev2, DeviceTemplates([t2]), sc2, 11, 11, O.BATCH_OPTIMIZE, 10)
+    want = O.search(orc2, [t2], sc2, 11, 11, kind=O.BATCH_OPTIMIZE, batch=10)
+    assert len(got) == len(want) and np.array_equal(got["tmpl_idx"], want["tmpl_idx"])
+    ok = ~np.isnan(want["score"])
+    assert np.array_equal(got["score"][ok].view(np.uint32), want["score"][ok].view(np.uint32))
+
+
+def test_api_end_to_end_like_reference(amd):
+    """tests/python/test_matching.py:45-104 of the reference, through the mirrored API."""
+    openfdcm = amd
+    threadpool = openfdcm.ThreadPool(4)
+    search_strategy = openfdcm.DefaultSearch(4, 10)
+    matcher = openfdcm.DefaultMatch()
+    penalizer = openfdcm.ExponentialPenalty(1.5)
+    tmpl = create_lines(10, 100)
+    for optimizer_strategy in (openfdcm.DefaultOptimize(threadpool), openfdcm.BatchOptimize(10, threadpool)):
+        scene_transform = np.array([[-1, 0, 100], [0, -1, 100]], dtype=np.float32)
+        scene = apply_transform(tmpl, scene_transform)
+        for distance in [openfdcm.distance.L2, openfdcm.distance.L1, openfdcm.distance.L2_SQUARED]:
+            params = openfdcm.Dt3CpuParameters(depth=30, dt3Coeff=5.0, padding=2.2, distance=distance)
+            fm = openfdcm.build_cpu_featuremap(scene, params, threadpool)
+            raw = openfdcm.search(matcher, search_strategy, optimizer_strategy, fm, [tmpl], scene)
+            best = openfdcm.sort_matches(raw)[0].transform
+            assert len(raw) == 80
+            assert np.allclose(scene_transform[:, :2], best[:, :2], atol=1e-5)
+            assert np.allclose(scene_transform[:, 2], best[:, 2], atol=1.0)
+            scene_transform = np.array([[1, 0, 0], [0, 1, 0]], dtype=np.float32)
+            scene = apply_transform(tmpl, scene_transform)
+            fm = openfdcm.build_cpu_featuremap(scene, params, threadpool)
+            raw = openfdcm.search(matcher, search_strategy, optimizer_strategy, fm, [tmpl], scene)
+            pen = openfdcm.penalize(penalizer, raw, openfdcm.get_template_lengths([tmpl]))
+            best = openfdcm.sort_matches(pen)[0].transform
+            assert len(raw) == 80
+            assert np.allclose(scene_transform[:, :2], best[:, :2], atol=1e-5)
+            assert np.allclose(scene_transform[:, 2], best[:, 2], atol=1.0)
+            fm0 = openfdcm.build_cpu_featuremap(np.zeros((4, 0)), params, threadpool)
+            assert len(openfdcm.search(matcher, search_strategy, optimizer_strategy, fm0, [tmpl], np.zeros((4, 0)))) == 0
+            scene = tmpl
+            fm = openfdcm.build_cpu_featuremap(scene, params, threadpool)
+            assert len(openfdcm.search(matcher, search_strategy, optimizer_strategy, fm, [], scene)) == 0
+            assert len(openfdcm.search(matcher, search_strategy, optimizer_strategy, fm, [np.zeros((4, 0))], scene)) == 0
+
+
+def test_adopted_volume_and_dt3_map_roundtrip(amd):
+    """Dt3Cpu(dt3map, translation, size) constructor + get_dt3_map (matching.cpp:72-84)."""
+    openfdcm = amd
+    scene = small_scene(128, 20, 21)
+    fm = openfdcm.build_cpu_featuremap(scene, openfdcm.Dt3CpuParameters(depth=8, dt3Coeff=5.0, padding=1.0))
+    d = fm.get_dt3_map()
+    orc = O.build(scene, depth=8, coeff=5.0, padding=1.0)
+    for i, k in enumerate(sorted(d)):
+        assert d[k].shape == (orc.H, orc.W)
+        assert np.array_equal(d[k], orc.slice(i))
+    fm2 = openfdcm.Dt3Cpu(d, fm.get_scene_translation(), fm.get_feature_size())
+    tm = [create_lines(6, 20)]
+    a = openfdcm.search(openfdcm.DefaultMatch(), openfdcm.DefaultSearch(3, 3), openfdcm.BatchOptimize(5), fm, tm, scene)
+    b = openfdcm.search(openfdcm.DefaultMatch(), openfdcm.DefaultSearch(3, 3), openfdcm.BatchOptimize(5), fm2, tm, scene)
+    assert len(a) == len(b) and all(x.score == y.score and x.tmpl_idx == y.tmpl_idx for x, y in zip(a, b))
