@@ -203,7 +203,7 @@ __global__ void __launch_bounds__(256) k_sweep_l1(float* __restrict__ vol, int W
 
 __global__ void k_sqrt(float* __restrict__ vol, size_t n) {  // only for staged (test) builds
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) vol[i] = __fsqrt_rn(vol[i]);
+    if (i < n) vol[i] = sqrtf(vol[i]);
 }
 
 // ------------------------------------------------------------------------------------------ K3
@@ -218,7 +218,7 @@ __global__ void k_propagate(float* __restrict__ vol, size_t npix, int m, const P
     const bool ok = p < npix;
     for (int j = 0; j < m; ++j) {
         float v = ok ? vol[(size_t)j * npix + p] : 0.f;
-        if (apply_sqrt) v = __fsqrt_rn(v);
+        if (apply_sqrt) v = sqrtf(v);
         S[j * bd + tid] = v;
     }
     for (int s = 0; s < nsteps; ++s) {
