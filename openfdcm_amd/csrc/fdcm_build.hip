@@ -5,13 +5,16 @@
 //
 // Kernels (W x H = feature size, m = slices, V = 4*m*W*H bytes):
 //   K0 k_seeds      clipped scene lines -> seed bitmap (1 bit per pixel, bits along y)   ~V/32
-//   K1 k_pass1      1-D distance along y from the bitmap (exact integers)               write V
-//   K2 k_pass2_l2   literal in-place lower-envelope pass along x (imgproc.h:91-130)      read V, write V
-//      k_sweep_l1   L1 min-plus sweeps along x (imgproc.h:137-146)                       read V, write V (x2)
+//   K1 k_coldesc    per column and 64-row chunk: seed bits + nearest seed before/after   ~V/16
+//   K2 k_pass2_l2   pass 1 (from descriptors) fused into the literal in-place lower-envelope
+//                   pass along x (imgproc.h:91-130)                                      write V
+//      k_l1_*       L1: forward sweep from descriptors (write V), backward sweep (read V, write V)
 //   K3 k_propagate  orientation propagation, 4m steps per pixel in LDS (+ sqrt for L2)   read V, write V
 //   K4 k_integral   directional prefix sum per slice, one sequential chain per thread    read V, write V
 // Compiled with -ffp-contract=off; divide and sqrt are the correctly rounded forms.
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "fdcm_internal.h"
@@ -68,14 +71,22 @@ __device__ __forceinline__ int wave_min(int v) {
     return v;
 }
 
-template <bool SQUARED>
-__global__ void __launch_bounds__(256) k_pass1(const unsigned long long* __restrict__ bitmap, float* __restrict__ vol,
-                                               int H, int HW64, long ncols) {
+// Column-chunk descriptor: for column (k, x) and the 64 rows [64c, 64c+64): the seed bits of the
+// chunk, the last seed row before it and the first seed row after it.  16 bytes per 64 pixels,
+// stored [k][c][x] so that a wave sweeping along x prefetches 64 columns with one coalesced load.
+struct __attribute__((aligned(16))) ColDesc {
+    unsigned long long word;
+    int prev;  // INT_MIN: none
+    int next;  // INT_MAX: none
+};
+
+__global__ void __launch_bounds__(256) k_coldesc(const unsigned long long* __restrict__ bitmap,
+                                                 ColDesc* __restrict__ desc, int W, int HW64, long ncols) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long col = (long)blockIdx.x * (blockDim.x >> 6) + wave;
+    const long col = (long)blockIdx.x * (blockDim.x >> 6) + wave;  // = k * W + x
     if (col >= ncols) return;
+    const long k = col / W, x = col - k * W;
     const unsigned long long* bw = bitmap + (size_t)col * HW64;
-    float* out = vol + (size_t)col * H;
     const int ngroups = (HW64 + 63) >> 6;  // groups of 64 words = 4096 rows
     int carry_prev = INT_MIN;              // last seed row in earlier groups
     for (int g = 0; g < ngroups; ++g) {
@@ -83,121 +94,314 @@ __global__ void __launch_bounds__(256) k_pass1(const unsigned long long* __restr
         const unsigned long long word = wi < HW64 ? bw[wi] : 0ull;
         const int last_i = word ? wi * 64 + 63 - __clzll(word) : INT_MIN;
         const int first_i = word ? wi * 64 + (__ffsll((long long)word) - 1) : INT_MAX;
-        // first seed row in later groups (rare: only when H > 4096)
-        int carry_next = INT_MAX;
+        int carry_next = INT_MAX;  // first seed row in later groups (only when H > 4096)
         for (int g2 = ngroups - 1; g2 > g; --g2) {
             const int wj = g2 * 64 + lane;
             const unsigned long long w2 = wj < HW64 ? bw[wj] : 0ull;
             carry_next = min(carry_next, wave_min(w2 ? wj * 64 + (__ffsll((long long)w2) - 1) : INT_MAX));
         }
-        const int prev_excl = max(wave_scan_max_excl(last_i, lane), carry_prev);
-        const int next_excl = min(wave_scan_min_excl_rev(first_i, lane), carry_next);
-        const int nchunks = min(64, HW64 - g * 64);
-        for (int c = 0; c < nchunks; ++c) {
-            const unsigned long long wc = __shfl(word, c);
-            const int pc = __shfl(prev_excl, c), nc = __shfl(next_excl, c);
-            const int y = (g * 64 + c) * 64 + lane;
-            int d = INT_MAX;
-            const unsigned long long below = wc & (~0ull >> (63 - lane));  // bits 0..lane
-            if (below) d = lane - (63 - __clzll(below));
-            else if (pc != INT_MIN) d = y - pc;
-            const unsigned long long above = wc >> lane;  // bits lane..63 shifted down
-            if (above) d = min(d, __ffsll((long long)above) - 1);
-            else if (nc != INT_MAX) d = min(d, nc - y);
-            if (y < H) {
-                float f = FLT_MAX;
-                if (d != INT_MAX) f = SQUARED ? (float)((long)d * (long)d) : (float)d;
-                out[y] = f;
-            }
-        }
+        ColDesc d;
+        d.word = word;
+        d.prev = max(wave_scan_max_excl(last_i, lane), carry_prev);
+        d.next = min(wave_scan_min_excl_rev(first_i, lane), carry_next);
+        if (wi < HW64) desc[((size_t)k * HW64 + wi) * W + x] = d;
         carry_prev = max(carry_prev, wave_max(last_i));
     }
 }
 
+// Pass 1 of distanceTransform (imgproc.h:178 / :186, along y) evaluated on the fly.  On a
+// 0 / FLT_MAX image the lower-envelope pass yields exactly the squared distance to the nearest
+// seed of the column (every envelope owner is a seed and owns itself), or FLT_MAX for a seedless
+// column; the L1 sweeps yield the plain distance.  Both are integers < 2^24, so this bit-scan
+// gives the reference's bits.  y = 64c + lane.
+template <bool SQUARED>
+__device__ __forceinline__ float column_value(unsigned long long wc, int pc, int nc, int lane, int y) {
+    int d = INT_MAX;
+    const unsigned long long below = wc & (~0ull >> (63 - lane));  // bits 0..lane
+    if (below) d = lane - (63 - __clzll(below));
+    else if (pc != INT_MIN) d = y - pc;
+    const unsigned long long above = wc >> lane;  // bits lane..63 shifted down
+    if (above) d = min(d, __ffsll((long long)above) - 1);
+    else if (nc != INT_MAX) d = min(d, nc - y);
+    if (d == INT_MAX) return FLT_MAX;
+    return SQUARED ? (float)((unsigned)d * (unsigned)d) : (float)d;
+}
+
+__device__ unsigned long long g_dbg[8192 * 4];
+
+__device__ __forceinline__ void desc_lane(const ColDesc& d, int j, unsigned long long& wc, int& pc, int& nc) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(d.word & 0xffffffffull), j);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(d.word >> 32), j);
+    wc = ((unsigned long long)hi << 32) | lo;
+    pc = __builtin_amdgcn_readlane(d.prev, j);
+    nc = __builtin_amdgcn_readlane(d.next, j);
+}
+
 // ------------------------------------------------------------------------------------------ K2
-// _distanceTransformColumnPassL2 along x (second call, imgproc.h:181-183), one thread per
-// (slice, row), followed literally: float intersections s, pop while s <= z[k], and the fill
-// that reads the image being overwritten (imgproc.h:122-128).  Lanes of a wave are consecutive
-// y, so every access to column x is a coalesced 256-byte segment.  The (v, f[v], z) stack lives
-// in HBM scratch, interleaved by thread ([slot][thread]); its top entry is kept in registers.
-__global__ void __launch_bounds__(256) k_pass2_l2(float* __restrict__ vol, int W, int H, long nrows,
-                                                  int* __restrict__ sv, float* __restrict__ sf,
-                                                  float* __restrict__ sz) {
-    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= nrows) return;
-    const long k = gid / H, y = gid - k * H;
-    float* row = vol + (size_t)k * W * H + y;  // element x at row[x * H]
-    const size_t H_ = (size_t)H, NT = (size_t)nrows;
+// Both 1-D passes of distanceTransform<float, L2 / L2_SQUARED> (imgproc.h:178-183) in one sweep
+// along x.  One wave per (slice k, 64-row chunk c[, sub-block of R rows]); lane = row.  The
+// pass-1 value of column q is recomputed from the column descriptor (64 columns staged in LDS per
+// 1 KiB load), so the sweep reads V/16 instead of V.  Pass 2 is followed literally: float
+// intersections s = ((f[q] + q^2) - f[v] - v^2) / (2q - 2v), pop while s <= z[k], and the fill
+// that reads the image being overwritten (imgproc.h:122-128); writes to column q are coalesced.
+//
+// The per-row (v, f[v], z) stack is a three-level structure: the two top entries live in
+// registers (the push/pop/push pattern of seedless columns never leaves them), the next C entries
+// in an LDS ring ([slot][row], conflict free), and only older entries spill to HBM scratch
+// ([slot][row], coalesced).  Inside the column loop nothing depends on a vector-memory load, so
+// stores (spills, results) are never waited for; refills from HBM are rare and self-contained.
+//
+// R = rows per wave (64, 32 or 16).  The chain per row is sequential, so a small volume has too
+// few rows to occupy 1024 SIMDs with full waves; with R < 64 lanes l and l + R run the same row
+// (same values, same addresses, identical control flow), which multiplies the number of waves
+// and leaves a longer LDS ring (C = 1024 / R entries) per row.
+template <int R>
+__global__ void __launch_bounds__(256) k_pass2_l2(const ColDesc* __restrict__ desc, float* __restrict__ vol, int W,
+                                                  int H, int HW64, long nwaves, int* __restrict__ sv,
+                                                  float* __restrict__ sf, float* __restrict__ sz, int dbg_phases) {
+    constexpr int C = 1024 / R;  // LDS ring entries per row
+    constexpr int NR = 4 * R;    // distinct rows per block
+    constexpr int SG = 16;       // staging entries per row for the fill
+    __shared__ int r_v[C][NR];
+    __shared__ float r_f[C][NR];
+    __shared__ float r_z[C][NR];
+    __shared__ int g_v[SG][NR];
+    __shared__ float g_f[SG][NR];
+    __shared__ float g_z[SG][NR];
+    __shared__ uint4 dsc[4][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long wid = (long)blockIdx.x * 4 + wave;
+    if (wid >= nwaves) return;  // wave-uniform
+    constexpr int SUB = 64 / R;  // waves per 64-row chunk
+    const long chunk = wid / SUB;
+    const int sub = (int)(wid - chunk * SUB);
+    const long k = chunk / HW64;
+    const int c = (int)(chunk - k * HW64);
+    const int bit = sub * R + (lane & (R - 1));  // row inside the chunk = bit of the seed word
+    const int urow = wave * R + (lane & (R - 1));  // row inside the block (LDS column)
+    const int y = c * 64 + bit;
+    const bool active = y < H && lane < R;
+    const long gid = wid * R + (lane & (R - 1));  // scratch row
+    const uint4* dp = reinterpret_cast<const uint4*>(desc + ((size_t)k * HW64 + c) * W);
+    float* row = vol + (size_t)k * W * H + (y < H ? y : 0);  // element x at row[x * H]
+    const size_t H_ = (size_t)H, NT = (size_t)nwaves * R;
     const float inf = f_inf();
     // ---- envelope construction (imgproc.h:101-121)
-    int tv = 0;
-    float tf = row[0], tz = -inf;
-    int below = 0;  // entries stored under the register-held top
-    for (int q = 1; q < W; ++q) {
-        const float fq = row[(size_t)q * H_];
-        const float q2 = (float)((long)q * (long)q);
+    int tv = 0, uv = 0;
+    float tf = 0.f, tz = -inf, uf = 0.f, uz = 0.f;
+    bool has_u = false;
+    int cnt = 0;     // entries below the register pair
+    int base = 0;    // entries [base, cnt) are in the LDS ring, [0, base) only in HBM
+    int gvalid = 0;  // entries [0, gvalid) have a valid HBM copy
+    // second register entry moves down into the ring as entry `cnt`; the oldest ring entry spills
+    auto push_down = [&](int v, float f, float z) {
+        if (cnt - base == C) {
+            if (base >= gvalid) {
+                const size_t slot = (size_t)base * NT + gid;
+                const int r = base & (C - 1);
+                sv[slot] = r_v[r][urow]; sf[slot] = r_f[r][urow]; sz[slot] = r_z[r][urow];
+                gvalid = base + 1;
+            }
+            ++base;
+        }
+        const int r = cnt & (C - 1);
+        r_v[r][urow] = v; r_f[r][urow] = f; r_z[r][urow] = z;
+        ++cnt;
+    };
+    // One column of the envelope construction for this lane's row (imgproc.h:108-120).
+    auto process_column = [&](int q, float fq) {
+        const float q2 = (float)((unsigned)q * (unsigned)q);
         while (true) {
-            const float s = (fq + q2 - tf - (float)((long)tv * (long)tv)) / (float)(2 * (long)q - 2 * (long)tv);
-            if (s > tz || below == 0) {  // below == 0 only guards non-finite inputs (z[0] = -inf)
-                const size_t slot = (size_t)below * NT + gid;
-                sv[slot] = tv; sf[slot] = tf; sz[slot] = tz;
-                ++below;
+            const float s = (fq + q2 - tf - (float)((unsigned)tv * (unsigned)tv)) / (float)(2 * q - 2 * tv);
+            // (!has_u && cnt == 0): the top is entry 0 whose z is -inf; only guards non-finite input
+            if (s > tz || (!has_u && cnt == 0)) {
+                if (has_u) push_down(uv, uf, uz);
+                uv = tv; uf = tf; uz = tz; has_u = true;
                 tv = q; tf = fq; tz = s;
                 break;
             }
-            --below;
-            const size_t slot = (size_t)below * NT + gid;
-            tv = sv[slot]; tf = sf[slot]; tz = sz[slot];
+            if (has_u) {
+                tv = uv; tf = uf; tz = uz; has_u = false;
+            } else {
+                if (cnt == base) {  // ring empty: bring one spilled entry back (rare)
+                    --base;
+                    const size_t slot = (size_t)base * NT + gid;
+                    const int r = base & (C - 1);
+                    r_v[r][urow] = sv[slot]; r_f[r][urow] = sf[slot]; r_z[r][urow] = sz[slot];
+                }
+                --cnt;
+                const int r = cnt & (C - 1);
+                tv = r_v[r][urow]; tf = r_f[r][urow]; tz = r_z[r][urow];
+                if (gvalid > cnt) gvalid = cnt;
+            }
+        }
+    };
+    const unsigned long long t_start = __builtin_amdgcn_s_memtime();
+    unsigned long long n_cols = 0, n_iter = 0;
+    uint4 dreg = dp[min(lane, W - 1)];
+    for (int q0 = 0; q0 < ((dbg_phases & 1) ? W : 0); q0 += 64) {
+        // lane j holds the descriptor of column q0 + j: one ballot tells which columns are seedless
+        const bool sl = (dreg.x | dreg.y) == 0u && (int)dreg.z == INT_MIN && (int)dreg.w == INT_MAX;
+        const unsigned long long smask = __ballot(sl);
+        dsc[wave][lane] = dreg;                    // the only wait on vector memory per 64 columns
+        dreg = dp[min(q0 + 64 + lane, W - 1)];     // next 64 descriptors, in flight during this chunk
+        const int jn = min(64, W - q0);
+        // Only columns that hold a seed enter the envelope.  A seedless column q (f = FLT_MAX, which
+        // absorbs every finite term: those are < 2^33 and ulp(FLT_MAX)/2 = 2^103) is pushed by the
+        // reference with z = FLT_MAX / (2(q - v_top)) >= 2^110 over a finite top (or z = +0 over a
+        // seedless entry 0) and is popped again by the very next column, seedless or not, because
+        // that column's intersection with it is -v^2/(2(q'-q)) <= 0 or about -FLT_MAX
+        // (imgproc.h:111-118); the entries below it are not touched in between.  If it is still on
+        // top at the end of the row it owns no pixel (z >= 2^110 > q at imgproc.h:124), or, over a
+        // seedless entry 0, it yields FLT_MAX like entry 0 itself.  So the fill's output does not
+        // depend on seedless columns other than column 0, and they are skipped.
+        unsigned long long todo = ~smask;
+        if (jn < 64) todo &= (1ull << jn) - 1ull;
+        if (q0 == 0) {  // v[0] = 0, z[0] = -inf (imgproc.h:103-105)
+            const uint4 d0 = dsc[wave][0];
+            tf = column_value<true>(((unsigned long long)d0.y << 32) | d0.x, (int)d0.z, (int)d0.w, bit, y);
+            todo &= ~1ull;
+        }
+        while (todo) {
+            const int j = __ffsll((long long)todo) - 1;
+            todo &= todo - 1ull;
+            const uint4 dj = dsc[wave][j];  // LDS broadcast
+            const float fq = column_value<true>(((unsigned long long)dj.y << 32) | dj.x, (int)dj.z, (int)dj.w, bit, y);
+            process_column(q0 + j, fq);
+            ++n_cols;
         }
     }
-    {
-        const size_t slot = (size_t)below * NT + gid;
-        sv[slot] = tv; sf[slot] = tf; sz[slot] = tz;
-    }
-    const int n_entries = below + 1;
-    // ---- fill (imgproc.h:122-128).  The owner's base value img(v_k) is read from the image in
-    // place when v_k lies behind q (already overwritten), else it is the original f[v_k].
+    const unsigned long long t_build = __builtin_amdgcn_s_memtime();
+    // ---- the register pair joins the ring: entries [base, n) are in LDS, [0, base) in HBM
+    if (has_u) push_down(uv, uf, uz);
+    push_down(tv, tf, tz);
+    const int n_entries = cnt;
+    if ((dbg_phases & 32) && lane == 0 && wid < 8192) { g_dbg[wid * 4] = t_build - t_start; g_dbg[wid * 4 + 1] = n_cols; g_dbg[wid * 4 + 2] = (unsigned long long)n_entries; g_dbg[wid*4+3] = t_start; }
+    if (!(dbg_phases & 2)) return;
+    // ---- fill (imgproc.h:122-128).  The owner's base value img(v_k) is the already overwritten
+    // g[v_k] when v_k lies behind q, else the original f[v_k].  Entries are consumed in order from
+    // LDS (ring, or a 16-entry staging window refilled from HBM for the spilled part); g at the
+    // positions of the next two owners is captured when q passes them, which replaces almost
+    // every read-back of the image.
+    int st0 = -SG;  // staging window holds entries [st0, st0 + SG)
+    auto fetch = [&](int i, int& v, float& f, float& z) {
+        if (i >= n_entries) { v = -1; f = 0.f; z = inf; return; }
+        if (i >= base) {
+            const int r = i & (C - 1);
+            v = r_v[r][urow]; f = r_f[r][urow]; z = r_z[r][urow];
+            return;
+        }
+        if (i >= st0 + SG) {  // refill the window with [i, i + SG) from HBM (rare, self-contained)
+            st0 = i;
+            int lv[SG];
+            float lf[SG], lz[SG];
+#pragma unroll
+            for (int e = 0; e < SG; ++e) {
+                const size_t slot = (size_t)min(i + e, base - 1) * NT + gid;
+                lv[e] = sv[slot]; lf[e] = sf[slot]; lz[e] = sz[slot];
+            }
+#pragma unroll
+            for (int e = 0; e < SG; ++e) { g_v[e][urow] = lv[e]; g_f[e][urow] = lf[e]; g_z[e][urow] = lz[e]; }
+        }
+        v = g_v[i - st0][urow]; f = g_f[i - st0][urow]; z = g_z[i - st0][urow];
+    };
+    int cv, av, bv;
+    float cf, cz, af, az, bf, bz;
+    fetch(0, cv, cf, cz);
+    fetch(1, av, af, az);
+    fetch(2, bv, bf, bz);
     int kk = 0;
-    int cv = sv[gid];
-    float cf = sf[gid];
-    float nz = n_entries > 1 ? sz[NT + gid] : inf;
-    bool fresh = true;
-    float base = 0.f;
+    float base_val = cf, ag = 0.f, bg = 0.f;
+    bool has_ag = false, has_bg = false;
     for (int q = 0; q < W; ++q) {
-        while (nz < (float)q) {
+        bool fresh = false;
+        while (az < (float)q) {
             ++kk;
-            const size_t slot = (size_t)kk * NT + gid;
-            cv = sv[slot]; cf = sf[slot];
-            nz = (kk + 1 < n_entries) ? sz[slot + NT] : inf;
-            fresh = true;
+            cv = av; cf = af;
+            base_val = ag; fresh = !has_ag;
+            av = bv; af = bf; az = bz; ag = bg; has_ag = has_bg;
+            fetch(kk + 2, bv, bf, bz);
+            has_bg = false;
         }
         if (fresh) {
-            base = (cv < q) ? row[(size_t)cv * H_] : cf;
-            fresh = false;
+            base_val = cf;
+            if (cv < q && y < H) {
+                // rare read-back of the image; consumed inside the branch so that the compiler's
+                // vmcnt wait stays here and the stores of the loop are never waited for
+                const float t = row[(size_t)cv * H_];
+                asm volatile("v_mov_b32 %0, %1" : "=v"(base_val) : "v"(t));
+            }
         }
-        const long dq = (long)q - (long)cv;
-        row[(size_t)q * H_] = base + (float)(dq * dq);
+        const unsigned dq = (unsigned)(q - cv);  // squared modulo 2^32: exact for |q - cv| < 2^16
+        const float g = base_val + (float)(dq * dq);
+        if (active) row[(size_t)q * H_] = g;
+        if (q == av) { ag = g; has_ag = true; }
+        if (q == bv) { bg = g; has_bg = true; }
     }
 }
 
-// _distanceTransformColumnPassL1 along x (imgproc.h:137-146): forward then backward
-// col(q) = min(col(q), col(q -+ 1) + 1), one thread per (slice, row).
-__global__ void __launch_bounds__(256) k_sweep_l1(float* __restrict__ vol, int W, int H, long nrows) {
+// distanceTransform<float, L1> (imgproc.h:176-181): the sweeps along y are the descriptor
+// distance (exact integers), the forward sweep along x runs on it directly (imgproc.h:138-140)
+// and writes V; the backward sweep (imgproc.h:142-145) reads that and writes the result in place.
+__global__ void __launch_bounds__(256) k_l1_forward(const ColDesc* __restrict__ desc, float* __restrict__ vol, int W,
+                                                    int H, int HW64, long nwaves) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const long wid = (long)blockIdx.x * 4 + (tid >> 6);
+    if (wid >= nwaves) return;
+    const long k = wid / HW64;
+    const int c = (int)(wid - k * HW64);
+    const int y = c * 64 + lane;
+    const bool active = y < H;
+    const ColDesc* dp = desc + ((size_t)k * HW64 + c) * W;
+    float* row = vol + (size_t)k * W * H + (active ? y : 0);
+    const size_t H_ = (size_t)H;
+    float run = 0.f;
+    ColDesc dcur = dp[min(lane, W - 1)];
+    for (int q0 = 0; q0 < W; q0 += 64) {
+        const ColDesc dnext = dp[min(q0 + 64 + lane, W - 1)];
+        const int jn = min(64, W - q0);
+        for (int j = 0; j < jn; ++j) {
+            unsigned long long wc;
+            int pc, nc;
+            desc_lane(dcur, j, wc, pc, nc);
+            const float cq = column_value<false>(wc, pc, nc, lane, y);
+            run = (q0 + j == 0) ? cq : std_min(cq, run + 1);
+            if (active) row[(size_t)(q0 + j) * H_] = run;
+        }
+        dcur = dnext;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_l1_backward(float* __restrict__ vol, int W, int H, long nrows) {
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= nrows) return;
     const long k = gid / H, y = gid - k * H;
     float* row = vol + (size_t)k * W * H + y;
     const size_t H_ = (size_t)H;
-    float run = row[0];
-    for (int q = 1; q < W; ++q) {
-        const float c = row[(size_t)q * H_];
-        run = std_min(c, run + 1);
-        row[(size_t)q * H_] = run;
-    }
-    for (int q = W - 2; q >= 0; --q) {
-        const float c = row[(size_t)q * H_];
-        run = std_min(c, run + 1);
-        row[(size_t)q * H_] = run;
+    constexpr int U = 16;
+    float va[U], vb[U];
+    // q runs W-2 .. 0; chunk t covers q = W-2-t*U-j.  Loads never alias earlier stores of the sweep.
+    auto fetch = [&](int t, float* v) {
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int q = W - 2 - t * U - j;
+            v[j] = q >= 0 ? row[(size_t)q * H_] : 0.f;
+        }
+    };
+    float run = row[(size_t)(W - 1) * H_];
+    fetch(0, va);
+    for (int t = 0; t * U < W - 1; ++t) {
+        fetch(t + 1, vb);
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int q = W - 2 - t * U - j;
+            if (q >= 0) {
+                run = std_min(va[j], run + 1);
+                row[(size_t)q * H_] = run;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j) va[j] = vb[j];
     }
 }
 
@@ -236,13 +440,21 @@ __global__ void k_propagate(float* __restrict__ vol, size_t npix, int m, const P
 // shifted by dy_i = round(i r) - round((i-1) r), into the current one; the shifts telescope, so
 // pixel (x_i, c + round(i r)) belongs to chain c and each chain is one sequential float32 sum.
 // One thread per chain; the order of additions is the reference's.
+// LP = active lanes (chains) per wave.  A chain is a dependent chain of float adds, so what
+// bounds the kernel is memory latency: every lane keeps NB*U loads in flight (NB register buffers
+// of U steps, each refilled right after it is consumed), and LP < 64 multiplies the waves when a
+// volume has too few chains to fill the chip.
+template <int LP>
 __global__ void __launch_bounds__(256) k_integral(float* __restrict__ vol, int W, int H,
                                                   const IntegralDesc* __restrict__ desc) {
+    constexpr int U = 8, NB = 6;
     const int k = blockIdx.y;
     const IntegralDesc d = desc[k];
     if (d.mode == 0) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane >= LP) return;
     float* img = vol + (size_t)k * W * H;
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int t = (blockIdx.x * 4 + wave) * LP + lane;
     const int steps = d.mode == 1 ? W : H;   // sweep length
     const int span = d.mode == 1 ? H : W;    // extent across chains
     const int last_off = (int)roundf((float)(steps - 1) * d.r);
@@ -250,20 +462,39 @@ __global__ void __launch_bounds__(256) k_integral(float* __restrict__ vol, int W
     const int c = cmin + t;
     if (c > cmax) return;
     const int start = d.s < 0 ? steps - 1 : 0;
+    // element (step i, offset o): mode 1 -> (x = a, y = o), mode 2 -> (x = o, y = a), a = start + i*s
+    const int stride_a = d.mode == 1 ? H : 1, stride_o = d.mode == 1 ? 1 : H;
     float acc = 0.f;
     bool started = false;
-    for (int i = 0; i < steps; ++i) {
-        const int o = c + (int)roundf((float)i * d.r);
-        if (o < 0 || o >= span) {
-            if (started) break;  // offsets are monotone: a chain that left never returns
-            continue;
+    // Loads of a chain never alias its earlier stores (each pixel belongs to one chain and is
+    // visited once), so values are fetched far ahead of the running sum.
+    int idx[NB][U];
+    float v[NB][U];
+    auto fetch = [&](int b, int i0) {
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int i = i0 + j;
+            const int o = c + (int)roundf((float)i * d.r);
+            const bool ok = i < steps && o >= 0 && o < span;
+            idx[b][j] = ok ? (start + i * d.s) * stride_a + o * stride_o : -1;
+            v[b][j] = ok ? img[idx[b][j]] : 0.f;
         }
-        const int a = start + i * d.s;
-        const size_t idx = d.mode == 1 ? (size_t)a * H + o : (size_t)o * H + a;
-        const float v = img[idx];
-        acc = started ? v + acc : v;
-        img[idx] = acc;
-        started = true;
+    };
+#pragma unroll
+    for (int b = 0; b < NB; ++b) fetch(b, b * U);
+    for (int i0 = 0; i0 < steps; i0 += NB * U) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                if (idx[b][j] >= 0) {
+                    acc = started ? v[b][j] + acc : v[b][j];
+                    img[idx[b][j]] = acc;
+                    started = true;
+                }
+            }
+            fetch(b, i0 + (NB + b) * U);
+        }
     }
 }
 
@@ -285,13 +516,19 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after) {
     fm->last_build = fdcm_build_timing{};
     if (plan.m == 0 || plan.W == 0) return;
     const int W = (int)plan.W, H = (int)plan.H, m = (int)plan.m;
-    if (plan.W > 65536 || plan.H > 65536) throw std::string("feature size above 65536 is not supported");
+    if (plan.W > 32768 || plan.H > 32768) throw std::string("feature size above 32768 is not supported");
     const int HW64 = (H + 63) / 64;
     const size_t npix = (size_t)W * H, nvox = npix * m;
     const long nrows = (long)m * H, ncols = (long)m * W;
     fm->vol.reserve(nvox * sizeof(float));
     fm->bitmap.reserve((size_t)ncols * HW64 * 8);
-    if (fm->distance != FDCM_L1) fm->stack.reserve((size_t)W * nrows * 12);
+    const long nchunks = (long)m * HW64;  // (slice, 64-row chunk) pairs
+    int R = 64;                            // rows per wave of the L2 sweep: keep >= 2048 waves in flight
+    while (R > 16 && nchunks * (64 / R) < 2048) R >>= 1;
+    if (getenv("FDCM_K2_ROWS")) R = atoi(getenv("FDCM_K2_ROWS"));
+    const long nwaves = fm->distance == FDCM_L1 ? nchunks : nchunks * (64 / R);
+    fm->coldesc.reserve((size_t)ncols * HW64 * sizeof(ColDesc));
+    if (fm->distance != FDCM_L1) fm->stack.reserve((size_t)W * nwaves * R * 12);
     // ---- plan upload: one pinned blob, one async copy
     auto align16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
     fm->off_raster = 0;
@@ -322,25 +559,27 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after) {
         hipLaunchKernelGGL(k_seeds, dim3((unsigned)fm->n_raster), dim3(256), 0, st, d_raster,
                            fm->bitmap.as<unsigned long long>(), W, H, HW64);
     FDCM_HIP(hipEventRecord(ev[1], st));
-    {
-        const unsigned blocks = (unsigned)((ncols + 3) / 4);
-        if (fm->distance == FDCM_L1)
-            hipLaunchKernelGGL(k_pass1<false>, dim3(blocks), dim3(256), 0, st, fm->bitmap.as<unsigned long long>(), vol,
-                               H, HW64, ncols);
-        else
-            hipLaunchKernelGGL(k_pass1<true>, dim3(blocks), dim3(256), 0, st, fm->bitmap.as<unsigned long long>(), vol,
-                               H, HW64, ncols);
-    }
+    ColDesc* d_desc = fm->coldesc.as<ColDesc>();
+    hipLaunchKernelGGL(k_coldesc, dim3((unsigned)((ncols + 3) / 4)), dim3(256), 0, st,
+                       fm->bitmap.as<unsigned long long>(), d_desc, W, HW64, ncols);
     FDCM_HIP(hipEventRecord(ev[2], st));
     {
-        const unsigned blocks = (unsigned)((nrows + 255) / 256);
+        const unsigned wblocks = (unsigned)((nwaves + 3) / 4);
         if (fm->distance == FDCM_L1) {
-            hipLaunchKernelGGL(k_sweep_l1, dim3(blocks), dim3(256), 0, st, vol, W, H, nrows);
+            hipLaunchKernelGGL(k_l1_forward, dim3(wblocks), dim3(256), 0, st, d_desc, vol, W, H, HW64, nwaves);
+            hipLaunchKernelGGL(k_l1_backward, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, st, vol, W, H, nrows);
         } else {
+            const size_t NT = (size_t)nwaves * R;
             int* sv = fm->stack.as<int>();
-            float* sf = (float*)(sv + (size_t)W * nrows);
-            float* sz = sf + (size_t)W * nrows;
-            hipLaunchKernelGGL(k_pass2_l2, dim3(blocks), dim3(256), 0, st, vol, W, H, nrows, sv, sf, sz);
+            float* sf = (float*)(sv + (size_t)W * NT);
+            float* sz = sf + (size_t)W * NT;
+            const int dbg = getenv("FDCM_DEBUG_K2_PHASES") ? atoi(getenv("FDCM_DEBUG_K2_PHASES")) : 3;
+            if (R == 64)
+                hipLaunchKernelGGL((k_pass2_l2<64>), dim3(wblocks), dim3(256), 0, st, d_desc, vol, W, H, HW64, nwaves, sv, sf, sz, dbg);
+            else if (R == 32)
+                hipLaunchKernelGGL((k_pass2_l2<32>), dim3(wblocks), dim3(256), 0, st, d_desc, vol, W, H, HW64, nwaves, sv, sf, sz, dbg);
+            else
+                hipLaunchKernelGGL((k_pass2_l2<16>), dim3(wblocks), dim3(256), 0, st, d_desc, vol, W, H, HW64, nwaves, sv, sf, sz, dbg);
         }
     }
     FDCM_HIP(hipEventRecord(ev[3], st));
@@ -359,12 +598,23 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after) {
     FDCM_HIP(hipEventRecord(ev[4], st));
     if (stop_after >= 3) {
         const int chains = 2 * (W > H ? W : H);
-        hipLaunchKernelGGL(k_integral, dim3((unsigned)((chains + 255) / 256), (unsigned)m), dim3(256), 0, st, vol, W, H,
-                           d_int);
+        int LP = 64;  // chains per wave: keep >= 4096 waves when the volume is small
+        while (LP > 16 && (long)m * ((chains + LP - 1) / LP) < 4096) LP >>= 1;
+        if (getenv("FDCM_K4_LANES")) LP = atoi(getenv("FDCM_K4_LANES"));
+        const dim3 grid((unsigned)((chains + 4 * LP - 1) / (4 * LP)), (unsigned)m);
+        if (LP == 64) hipLaunchKernelGGL(k_integral<64>, grid, dim3(256), 0, st, vol, W, H, d_int);
+        else if (LP == 32) hipLaunchKernelGGL(k_integral<32>, grid, dim3(256), 0, st, vol, W, H, d_int);
+        else hipLaunchKernelGGL(k_integral<16>, grid, dim3(256), 0, st, vol, W, H, d_int);
     }
     FDCM_HIP(hipEventRecord(ev[5], st));
     FDCM_HIP(hipGetLastError());
     FDCM_HIP(hipStreamSynchronize(st));
+    if (getenv("FDCM_DEBUG_DUMP")) {
+        static unsigned long long h[8192 * 4];
+        FDCM_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_dbg), sizeof h));
+        FILE* f = fopen(getenv("FDCM_DEBUG_DUMP"), "wb");
+        if (f) { fwrite(h, 1, sizeof h, f); fclose(f); }
+    }
     const auto t1 = std::chrono::steady_clock::now();
     fdcm_build_timing& bt = fm->last_build;
     bt.total_ms = std::chrono::duration<float, std::milli>(t1 - t0).count();
