@@ -13,8 +13,6 @@
 //   K4 k_integral   directional prefix sum per slice, one sequential chain per thread    read V, write V
 // Compiled with -ffp-contract=off; divide and sqrt are the correctly rounded forms.
 #include <chrono>
-#include <cstdio>
-#include <cstdlib>
 #include <cstring>
 
 #include "fdcm_internal.h"
@@ -127,8 +125,6 @@ __device__ __forceinline__ float column_value(unsigned long long wc, int pc, int
     return SQUARED ? (float)((unsigned)d * (unsigned)d) : (float)d;
 }
 
-__device__ unsigned long long g_dbg[8192 * 4];
-
 __device__ __forceinline__ void desc_lane(const ColDesc& d, int j, unsigned long long& wc, int& pc, int& nc) {
     const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(d.word & 0xffffffffull), j);
     const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(d.word >> 32), j);
@@ -158,7 +154,7 @@ __device__ __forceinline__ void desc_lane(const ColDesc& d, int j, unsigned long
 template <int R>
 __global__ void __launch_bounds__(256) k_pass2_l2(const ColDesc* __restrict__ desc, float* __restrict__ vol, int W,
                                                   int H, int HW64, long nwaves, int* __restrict__ sv,
-                                                  float* __restrict__ sf, float* __restrict__ sz, int dbg_phases) {
+                                                  float* __restrict__ sf, float* __restrict__ sz) {
     constexpr int C = 1024 / R;  // LDS ring entries per row
     constexpr int NR = 4 * R;    // distinct rows per block
     constexpr int SG = 16;       // staging entries per row for the fill
@@ -236,10 +232,8 @@ __global__ void __launch_bounds__(256) k_pass2_l2(const ColDesc* __restrict__ de
             }
         }
     };
-    const unsigned long long t_start = __builtin_amdgcn_s_memtime();
-    unsigned long long n_cols = 0, n_iter = 0;
     uint4 dreg = dp[min(lane, W - 1)];
-    for (int q0 = 0; q0 < ((dbg_phases & 1) ? W : 0); q0 += 64) {
+    for (int q0 = 0; q0 < W; q0 += 64) {
         // lane j holds the descriptor of column q0 + j: one ballot tells which columns are seedless
         const bool sl = (dreg.x | dreg.y) == 0u && (int)dreg.z == INT_MIN && (int)dreg.w == INT_MAX;
         const unsigned long long smask = __ballot(sl);
@@ -268,16 +262,12 @@ __global__ void __launch_bounds__(256) k_pass2_l2(const ColDesc* __restrict__ de
             const uint4 dj = dsc[wave][j];  // LDS broadcast
             const float fq = column_value<true>(((unsigned long long)dj.y << 32) | dj.x, (int)dj.z, (int)dj.w, bit, y);
             process_column(q0 + j, fq);
-            ++n_cols;
         }
     }
-    const unsigned long long t_build = __builtin_amdgcn_s_memtime();
     // ---- the register pair joins the ring: entries [base, n) are in LDS, [0, base) in HBM
     if (has_u) push_down(uv, uf, uz);
     push_down(tv, tf, tz);
     const int n_entries = cnt;
-    if ((dbg_phases & 32) && lane == 0 && wid < 8192) { g_dbg[wid * 4] = t_build - t_start; g_dbg[wid * 4 + 1] = n_cols; g_dbg[wid * 4 + 2] = (unsigned long long)n_entries; g_dbg[wid*4+3] = t_start; }
-    if (!(dbg_phases & 2)) return;
     // ---- fill (imgproc.h:122-128).  The owner's base value img(v_k) is the already overwritten
     // g[v_k] when v_k lies behind q, else the original f[v_k].  Entries are consumed in order from
     // LDS (ring, or a 16-entry staging window refilled from HBM for the spilled part); g at the
@@ -513,6 +503,7 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after) {
     hipStream_t st = fm->stream;
     fm->W = plan.W; fm->H = plan.H; fm->m = plan.m; fm->tx = plan.tx; fm->ty = plan.ty;
     fm->keys = plan.keys;
+    fm->vol_t_valid = false;
     fm->last_build = fdcm_build_timing{};
     if (plan.m == 0 || plan.W == 0) return;
     const int W = (int)plan.W, H = (int)plan.H, m = (int)plan.m;
@@ -525,7 +516,6 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after) {
     const long nchunks = (long)m * HW64;  // (slice, 64-row chunk) pairs
     int R = 64;                            // rows per wave of the L2 sweep: keep >= 2048 waves in flight
     while (R > 16 && nchunks * (64 / R) < 2048) R >>= 1;
-    if (getenv("FDCM_K2_ROWS")) R = atoi(getenv("FDCM_K2_ROWS"));
     const long nwaves = fm->distance == FDCM_L1 ? nchunks : nchunks * (64 / R);
     fm->coldesc.reserve((size_t)ncols * HW64 * sizeof(ColDesc));
     if (fm->distance != FDCM_L1) fm->stack.reserve((size_t)W * nwaves * R * 12);
@@ -573,13 +563,12 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after) {
             int* sv = fm->stack.as<int>();
             float* sf = (float*)(sv + (size_t)W * NT);
             float* sz = sf + (size_t)W * NT;
-            const int dbg = getenv("FDCM_DEBUG_K2_PHASES") ? atoi(getenv("FDCM_DEBUG_K2_PHASES")) : 3;
             if (R == 64)
-                hipLaunchKernelGGL((k_pass2_l2<64>), dim3(wblocks), dim3(256), 0, st, d_desc, vol, W, H, HW64, nwaves, sv, sf, sz, dbg);
+                hipLaunchKernelGGL((k_pass2_l2<64>), dim3(wblocks), dim3(256), 0, st, d_desc, vol, W, H, HW64, nwaves, sv, sf, sz);
             else if (R == 32)
-                hipLaunchKernelGGL((k_pass2_l2<32>), dim3(wblocks), dim3(256), 0, st, d_desc, vol, W, H, HW64, nwaves, sv, sf, sz, dbg);
+                hipLaunchKernelGGL((k_pass2_l2<32>), dim3(wblocks), dim3(256), 0, st, d_desc, vol, W, H, HW64, nwaves, sv, sf, sz);
             else
-                hipLaunchKernelGGL((k_pass2_l2<16>), dim3(wblocks), dim3(256), 0, st, d_desc, vol, W, H, HW64, nwaves, sv, sf, sz, dbg);
+                hipLaunchKernelGGL((k_pass2_l2<16>), dim3(wblocks), dim3(256), 0, st, d_desc, vol, W, H, HW64, nwaves, sv, sf, sz);
         }
     }
     FDCM_HIP(hipEventRecord(ev[3], st));
@@ -600,7 +589,6 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after) {
         const int chains = 2 * (W > H ? W : H);
         int LP = 64;  // chains per wave: keep >= 4096 waves when the volume is small
         while (LP > 16 && (long)m * ((chains + LP - 1) / LP) < 4096) LP >>= 1;
-        if (getenv("FDCM_K4_LANES")) LP = atoi(getenv("FDCM_K4_LANES"));
         const dim3 grid((unsigned)((chains + 4 * LP - 1) / (4 * LP)), (unsigned)m);
         if (LP == 64) hipLaunchKernelGGL(k_integral<64>, grid, dim3(256), 0, st, vol, W, H, d_int);
         else if (LP == 32) hipLaunchKernelGGL(k_integral<32>, grid, dim3(256), 0, st, vol, W, H, d_int);
@@ -609,12 +597,6 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after) {
     FDCM_HIP(hipEventRecord(ev[5], st));
     FDCM_HIP(hipGetLastError());
     FDCM_HIP(hipStreamSynchronize(st));
-    if (getenv("FDCM_DEBUG_DUMP")) {
-        static unsigned long long h[8192 * 4];
-        FDCM_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_dbg), sizeof h));
-        FILE* f = fopen(getenv("FDCM_DEBUG_DUMP"), "wb");
-        if (f) { fwrite(h, 1, sizeof h, f); fclose(f); }
-    }
     const auto t1 = std::chrono::steady_clock::now();
     fdcm_build_timing& bt = fm->last_build;
     bt.total_ms = std::chrono::duration<float, std::milli>(t1 - t0).count();

@@ -100,6 +100,8 @@ struct fdcm_featuremap {
     std::vector<float> keys;
     // device state
     fdcm::DevBuf vol;      // m*W*H float, [k][x][y]
+    fdcm::DevBuf vol_t;    // [k][y][x] copy used by the search for candidates stepping along x
+    bool vol_t_valid = false;
     fdcm::DevBuf bitmap;   // m*W*ceil(H/64) uint64 seed bits along y
     fdcm::DevBuf coldesc;  // m*ceil(H/64)*W column-chunk descriptors (16 B)
     fdcm::DevBuf stack;    // K2 scratch: per row a (v, f, z) stack of W entries

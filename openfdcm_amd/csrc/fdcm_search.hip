@@ -1,13 +1,21 @@
 // fdcm_search.hip -- search<DefaultMatch> + DefaultSearch + DefaultOptimize/BatchOptimize on gfx950
 // (defaultmatch.cpp:32-89, defaultsearch.cpp:29-49, batchoptimize.cpp:6-123, dt3cpu.cpp:119-179).
 //
-// One wavefront per aligned candidate (template t, template line j, scene line i, alignment).
-// The wave builds the candidate itself -- align(), transform(), orientation bins with the glibc
-// atanf restatement, bounding box, rasterizeVector, minmaxTranslation -- keeps the aligned lines in
-// LDS, and then replays the optimiser's batches: lane b scores translation multiplier k0 + b as
-// sum_i |I[bin_i](p1_i + t) - I[bin_i](p2_i + t)| with two 4-byte gathers per line from the DT3
-// volume, added in Eigen's VectorXf::sum() order so the float32 score -- and therefore every
-// early-exit decision -- is the reference's bit for bit.
+// One wavefront per aligned candidate (template t, template line j, scene line i, alignment); the
+// waves of a workgroup share one template, whose lines, plus the scene tables and the orientation
+// keys, are staged in LDS once per workgroup.  A wave builds its candidate itself -- align(),
+// transform(), orientation bins with the glibc atanf restatement, bounding box, rasterizeVector,
+// minmaxTranslation -- keeps the aligned lines in LDS, and then replays the optimiser.
+//
+// Scoring is the gather-bound part: sum_i |I[bin_i](p1_i + t) - I[bin_i](p2_i + t)| with two
+// 4-byte gathers per line from the DT3 volume.  Two lanes share one translation (the two packet
+// accumulators of Eigen's VectorXf::sum()), so one round scores up to 32 translations with all
+// gathers of a lane in flight together.  The first round scores translation 0 and the first
+// WIN multipliers of BOTH directions; the reference's exit rule (batches, the un-reset
+// scores.back(), first-minimum ties) is then replayed on the scores, and further rounds run only
+// for candidates whose descent continues.  Scores are added in Eigen's order, so they -- and
+// every decision -- are the reference's bit for bit; translations scored speculatively but never
+// reached by the rule are simply not read.
 #include <algorithm>
 #include <chrono>
 #include <cstring>
@@ -19,7 +27,8 @@ namespace fdcm {
 
 struct SearchParams {
     // feature map
-    const float* vol;
+    const float* vol;    // [k][x][y]
+    const float* vol_t;  // [k][y][x] copy for candidates that step along x
     const float* keys;
     int W, H, m;
     float tx, ty;
@@ -37,17 +46,20 @@ struct SearchParams {
     // strategy
     int maxT, maxS, window;
     int optimizer;
-    long long batch;
+    int batch;  // >= 1
+    int win;    // multipliers scored per direction and round (multiple of batch when batch <= 15)
     int base;
     // candidates
     const long long* cand_offsets;  // T+1
-    long long ncand;
-    int lds_lines;  // capacity (lines) of the per-wave LDS area
+    int bpt;                        // workgroups per template
+    int lds_lines;                  // capacity (lines) of the LDS template / aligned-line areas
     // outputs
     fdcm_match* records;
     int* flags;
-    unsigned long long* counters;  // [0] translations evaluated, [1] volume reads
+    unsigned long long* counters;  // [0] translations evaluated by the rule, [1] volume reads, [2] matches
 };
+
+static constexpr int kWavesPerBlock = 4;
 
 __device__ __forceinline__ float wave_min_f(float v) {
     for (int d = 32; d >= 1; d >>= 1) v = std_min(v, __shfl_xor(v, d));
@@ -58,86 +70,207 @@ __device__ __forceinline__ float wave_max_f(float v) {
     return v;
 }
 
-// evaluate<Dt3Cpu> for one translation, dt3cpu.cpp:153-175.  L = per-wave LDS lines
+// evaluate<Dt3Cpu> for one line and one translation, dt3cpu.cpp:153-173.  L = per-wave LDS lines
 // (x1,y1,x2,y2,bin), off = sceneTranslation + translation.
+// XF: read the x-fastest copy (W and H are passed swapped by the caller: the copy is [k][y][x]).
+template <bool XF>
 __device__ __forceinline__ float line_value(const float* __restrict__ vol, const float* L, int i, float offx,
                                             float offy, size_t W, size_t H) {
     const float* l = L + 5 * i;
     const int x1 = (int)(l[0] + offx), y1 = (int)(l[1] + offy);  // translate then cast<int>()
     const int x2 = (int)(l[2] + offx), y2 = (int)(l[3] + offy);
-    const size_t sb = (size_t)__float_as_int(l[4]) * W;
-    const float a = vol[(sb + (size_t)x1) * H + (size_t)y1];
-    const float b = vol[(sb + (size_t)x2) * H + (size_t)y2];
+    const size_t bin = (size_t)__float_as_int(l[4]);
+    float a, b;
+    if (XF) {
+        a = vol[(bin * H + (size_t)y1) * W + (size_t)x1];
+        b = vol[(bin * H + (size_t)y2) * W + (size_t)x2];
+    } else {
+        a = vol[(bin * W + (size_t)x1) * H + (size_t)y1];
+        b = vol[(bin * W + (size_t)x2) * H + (size_t)y2];
+    }
     return f_abs(a - b);
 }
 
-// score_per_line.sum(): Eigen 3.4.0 redux (Redux.h, LinearVectorizedTraversal, Packet4f):
-// two packet accumulators over blocks of 8, an optional trailing packet, predux as
-// (p0+p2)+(p1+p3), then the scalar tail in order.
-__device__ __forceinline__ float score_translation(const float* __restrict__ vol, const float* L, int n, float offx,
-                                                   float offy, size_t W, size_t H) {
-    if (n == 0) return 0.f;
+// score_per_line.sum() (dt3cpu.cpp:175): Eigen 3.4.0 redux (Redux.h, LinearVectorizedTraversal,
+// Packet4f): p0 = packet(0), p1 = packet(4); blocks of 8: p0 += packet(i), p1 += packet(i+4);
+// p0 += p1; optional trailing packet; predux (p0+p2)+(p1+p3); scalar tail in order.
+// Lane h = 0 owns p0, lane h = 1 owns p1 of the same translation; the result is valid in h = 0.
+template <bool XF>
+__device__ __forceinline__ float pair_score(const float* __restrict__ vol, const float* L, int n, float offx,
+                                            float offy, size_t W, size_t H, int h, bool active) {
     const int aligned2 = (n / 8) * 8, aligned = (n / 4) * 4;
-    float res;
-    if (aligned) {
-        float p0[4], p1[4];
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};  // 0 + v == v exactly (v >= +0)
+    if (active) {
+        if (aligned >= 8) {
+            const int nblk = aligned2 / 8;
+#pragma unroll 4
+            for (int i = 0; i < nblk; ++i) {
+                const int b = 8 * i + 4 * h;
+                float v[4];
 #pragma unroll
-        for (int l = 0; l < 4; ++l) p0[l] = line_value(vol, L, l, offx, offy, W, H);
-        if (aligned > 4) {
+                for (int l = 0; l < 4; ++l) v[l] = line_value<XF>(vol, L, b + l, offx, offy, W, H);
 #pragma unroll
-            for (int l = 0; l < 4; ++l) p1[l] = line_value(vol, L, 4 + l, offx, offy, W, H);
-            for (int idx = 8; idx < aligned2; idx += 8) {
-                float a[8];
-#pragma unroll
-                for (int l = 0; l < 8; ++l) a[l] = line_value(vol, L, idx + l, offx, offy, W, H);
-#pragma unroll
-                for (int l = 0; l < 4; ++l) { p0[l] = p0[l] + a[l]; p1[l] = p1[l] + a[4 + l]; }
+                for (int l = 0; l < 4; ++l) acc[l] = acc[l] + v[l];
             }
+        } else if (aligned == 4 && h == 0) {
 #pragma unroll
-            for (int l = 0; l < 4; ++l) p0[l] = p0[l] + p1[l];
-            if (aligned > aligned2) {
-#pragma unroll
-                for (int l = 0; l < 4; ++l) p0[l] = p0[l] + line_value(vol, L, aligned2 + l, offx, offy, W, H);
-            }
+            for (int l = 0; l < 4; ++l) acc[l] = line_value<XF>(vol, L, l, offx, offy, W, H);
         }
-        res = (p0[0] + p0[2]) + (p0[1] + p0[3]);
-        for (int idx = aligned; idx < n; ++idx) res = res + line_value(vol, L, idx, offx, offy, W, H);
-    } else {
-        res = line_value(vol, L, 0, offx, offy, W, H);
-        for (int idx = 1; idx < n; ++idx) res = res + line_value(vol, L, idx, offx, offy, W, H);
+    }
+    float res = 0.f;
+    if (aligned >= 8) {
+#pragma unroll
+        for (int l = 0; l < 4; ++l) acc[l] = acc[l] + __shfl_xor(acc[l], 1);  // h = 0: p0 + p1
+    }
+    if (active && h == 0) {
+        if (aligned) {
+            if (aligned >= 8 && aligned > aligned2) {
+#pragma unroll
+                for (int l = 0; l < 4; ++l) acc[l] = acc[l] + line_value<XF>(vol, L, aligned2 + l, offx, offy, W, H);
+            }
+            res = (acc[0] + acc[2]) + (acc[1] + acc[3]);
+            for (int idx = aligned; idx < n; ++idx) res = res + line_value<XF>(vol, L, idx, offx, offy, W, H);
+        } else if (n > 0) {
+            res = line_value<XF>(vol, L, 0, offx, offy, W, H);
+            for (int idx = 1; idx < n; ++idx) res = res + line_value<XF>(vol, L, idx, offx, offy, W, H);
+        }
     }
     return res;
 }
 
+struct OptState {
+    const float* L;  // aligned lines of the candidate (LDS)
+    float* sc;       // score window (LDS): [0, WIN) positive, [WIN, 2 WIN) negative, [2 WIN] translation 0
+    int n_t, lane, B, WIN;
+    bool batch_rule;
+    size_t W, H;
+    float tx, ty, savx, savy;
+    long long lim_p, lim_n;
+};
+
+// Score multipliers k_from, k_from + dir, ... (cnt of them) into sc[dst ..]; with_zero additionally
+// scores translation (0,0) into sc[2 WIN].  32 translations per gather round.
+template <bool XF>
+__device__ __forceinline__ void score_range(const float* __restrict__ vol, const OptState& o, int dir, long long k_from,
+                                            int cnt, int dst, bool with_zero) {
+    const int h = o.lane & 1, slot = o.lane >> 1;
+    const int total = cnt + (with_zero ? 1 : 0);
+    for (int s0 = 0; s0 < total; s0 += 32) {
+        const int idx = s0 + slot - (with_zero ? 1 : 0);  // -1 = the zero translation
+        const bool act = idx < cnt;
+        const long long k = idx < 0 ? 0 : k_from + (long long)dir * idx;
+        // translation = float(k) * scaled_align_vec (:58/:81); Point2{0,0} for the initial score (:36)
+        const float trx = idx < 0 ? 0.f : (float)k * o.savx, try_ = idx < 0 ? 0.f : (float)k * o.savy;
+        const float s = pair_score<XF>(vol, o.L, o.n_t, o.tx + trx, o.ty + try_, o.W, o.H, h, act);
+        if (act && h == 0) o.sc[idx < 0 ? 2 * o.WIN : dst + idx] = s;
+    }
+}
+
+// optimize<BatchOptimize / DefaultOptimize> for one candidate (batchoptimize.cpp:36-98,
+// defaultoptimize.cpp:36-66): speculative scoring in windows, literal replay of the rule.
+template <bool XF>
+__device__ __forceinline__ void optimise(const float* __restrict__ vol, const OptState& o, float& best, long long& best_k,
+                                         unsigned long long& n_eval) {
+    const int WIN = o.WIN, B = o.B;
+    const int h = o.lane & 1, slot = o.lane >> 1;
+    // ---- round 1: translation 0 and the first WIN multipliers of both directions
+    const int have_p = (int)min<long long>(WIN, o.lim_p >= 1 ? o.lim_p : 0);
+    const int have_n = (int)min<long long>(WIN, o.lim_n <= -1 ? -o.lim_n : 0);
+    if (1 + have_p + have_n <= 32) {
+        // one gather round: slot 0 = zero, then positives, then negatives
+        const int idx = slot - 1;
+        const bool is_p = idx >= 0 && idx < have_p, is_n = idx >= have_p && idx < have_p + have_n;
+        const bool act = slot == 0 || is_p || is_n;
+        const long long k = is_p ? 1 + idx : (is_n ? -1 - (idx - have_p) : 0);
+        const float trx = slot == 0 ? 0.f : (float)k * o.savx, try_ = slot == 0 ? 0.f : (float)k * o.savy;
+        const float s = pair_score<XF>(vol, o.L, o.n_t, o.tx + trx, o.ty + try_, o.W, o.H, h, act);
+        if (act && h == 0) o.sc[slot == 0 ? 2 * WIN : (is_p ? idx : WIN + (idx - have_p))] = s;
+    } else {
+        score_range<XF>(vol, o, +1, 1, have_p, 0, true);
+        score_range<XF>(vol, o, -1, -1, have_n, WIN, false);
+    }
+    const float init = o.sc[2 * WIN];
+    n_eval += 1;
+    best = init;
+    float back = init;  // scores.back(): NOT reset between the two directions (batchoptimize.cpp:73)
+    for (int dir = 1; dir >= -1; dir -= 2) {
+        const long long lim = dir > 0 ? o.lim_p : o.lim_n;
+        const int off = dir > 0 ? 0 : WIN;
+        long long win0 = dir;                       // multiplier held in sc[off]
+        int have = dir > 0 ? have_p : have_n;       // multipliers available from win0 on
+        for (long long k0 = dir; dir > 0 ? k0 <= lim : k0 >= lim; k0 += (long long)dir * B) {
+            long long nb = dir > 0 ? (lim - k0 + 1) : (k0 - lim + 1);
+            if (nb > B) nb = B;
+            // std::min_element over the batch (first minimum) and its last element, :63-70 / :86-93
+            float bmin = 0.f, blast = 0.f;
+            long long bmin_k = 0;
+            for (long long c0 = 0; c0 < nb;) {
+                long long rel = dir > 0 ? (k0 + c0 - win0) : (win0 - (k0 - c0));  // index in the window
+                if (rel >= have) {  // the rule walks on: score the next window of this direction
+                    win0 = k0 + dir * c0;
+                    const long long left = dir > 0 ? (lim - win0 + 1) : (win0 - lim + 1);
+                    have = (int)min<long long>(WIN, left);
+                    score_range<XF>(vol, o, dir, win0, have, off, false);
+                    rel = 0;
+                }
+                const int take = (int)min<long long>(nb - c0, have - rel);
+                for (int e = 0; e < take; ++e) {
+                    const float s = o.sc[off + (int)rel + e];
+                    if ((c0 == 0 && e == 0) || s < bmin) { bmin = s; bmin_k = k0 + dir * (c0 + e); }
+                    blast = s;
+                }
+                c0 += take;
+            }
+            n_eval += (unsigned long long)nb;
+            if (bmin > back) break;                 // :65 / :88
+            back = bmin;                            // keep (translation, score)
+            if (bmin < best) { best = bmin; best_k = bmin_k; }  // first argmin over kept scores, :97
+            if (o.batch_rule && bmin < blast) break;  // :70 / :93
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) k_search(const SearchParams P) {
     extern __shared__ float lds[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long long cand = (long long)blockIdx.x * (blockDim.x >> 6) + wave;
-    if (cand >= P.ncand) return;  // wave-uniform
-    float* L = lds + (size_t)wave * P.lds_lines * 5;
-
-    // ---- which candidate: template t, sorted template line j, window slot wi, alignment flip
-    int lo = 0, hi = P.T;  // last t with cand_offsets[t] <= cand
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (P.cand_offsets[mid] <= cand) lo = mid; else hi = mid;
-    }
-    const int t = lo;
-    const int local = (int)(cand - P.cand_offsets[t]);
-    const int flip = local & 1, pair = local >> 1;
-    const int j = pair / P.window, wi = pair - j * P.window;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int t = blockIdx.x / P.bpt;
+    const int local = (blockIdx.x - t * P.bpt) * kWavesPerBlock + wave;
     const long long l0 = P.toffsets[t];
     const int n_t = (int)(P.toffsets[t + 1] - l0);
+    const int count_t = 2 * min(n_t, P.maxT) * P.window;
+    // ---- LDS carve-up (floats): keys | scene sorted len | scene sorted idx | scene lines |
+    //      template lines | template sorted | template lengths | per-wave aligned lines | per-wave scores
+    float* s_keys = lds;
+    float* s_slen = s_keys + P.m;
+    int* s_sidx = (int*)(s_slen + P.n_s);
+    float* s_sl = (float*)(s_sidx + P.n_s);
+    float* s_tl = s_sl + 4 * P.n_s;
+    int* s_ts = (int*)(s_tl + 4 * P.lds_lines);
+    float* s_tlen = (float*)(s_ts + P.lds_lines);
+    float* L = s_tlen + P.lds_lines + (size_t)wave * P.lds_lines * 5;
+    float* sc = s_tlen + P.lds_lines + (size_t)kWavesPerBlock * P.lds_lines * 5 + (size_t)wave * (2 * P.win + 1);
+    for (int i = tid; i < P.m; i += 256) s_keys[i] = P.keys[i];
+    for (int i = tid; i < P.n_s; i += 256) { s_slen[i] = P.s_sorted_len[i]; s_sidx[i] = P.s_sorted_idx[i]; }
+    for (int i = tid; i < 4 * P.n_s; i += 256) s_sl[i] = P.slines[i];
+    for (int i = tid; i < 4 * n_t; i += 256) s_tl[i] = P.tlines[l0 * 4 + i];
+    for (int i = tid; i < n_t; i += 256) { s_ts[i] = P.tsorted[l0 + i]; s_tlen[i] = P.tlengths[l0 + i]; }
+    __syncthreads();
+    if (local >= count_t) return;  // wave-uniform
+    const long long cand = P.cand_offsets[t] + local;
+
+    // ---- which candidate: sorted template line j, window slot wi, alignment flip
+    const int flip = local & 1, pair = local >> 1;
+    const int j = pair / P.window, wi = pair - j * P.window;
     // establishSearchStrategy<DefaultSearch>, defaultsearch.cpp:38-46
-    const int tl_local = P.tsorted[l0 + j];
-    const float tlen = P.tlengths[l0 + tl_local];
-    const int centre = binary_search_greater(P.s_sorted_len, P.n_s, tlen);
+    const int tl_local = s_ts[j];
+    const float tlen = s_tlen[tl_local];
+    const int centre = binary_search_greater(s_slen, P.n_s, tlen);
     int rb, re;
     centered_range(centre, P.n_s, P.maxS, rb, re);
-    const int scene_idx = P.s_sorted_idx[rb + wi];
+    const int scene_idx = s_sidx[rb + wi];
     float tl[4], sl[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) { tl[c] = P.tlines[(l0 + tl_local) * 4 + c]; sl[c] = P.slines[(size_t)scene_idx * 4 + c]; }
+    for (int c = 0; c < 4; ++c) { tl[c] = s_tl[tl_local * 4 + c]; sl[c] = s_sl[scene_idx * 4 + c]; }
     // align + transform, defaultmatch.cpp:59-67
     float T1[6], T2[6], T[6];
     align_pair(tl, sl, T1, T2);
@@ -145,19 +278,17 @@ __global__ void __launch_bounds__(256) k_search(const SearchParams P) {
     for (int c = 0; c < 6; ++c) T[c] = flip ? T2[c] : T1[c];
     float mnx = f_inf(), mny = f_inf(), mxx = -f_inf(), mxy = -f_inf();
     for (int i = lane; i < n_t; i += 64) {
-        const float* p = P.tlines + (l0 + i) * 4;
+        const float* p = s_tl + 4 * i;
         const float x1 = (T[0] * p[0] + T[1] * p[1]) + T[2], y1 = (T[3] * p[0] + T[4] * p[1]) + T[5];
         const float x2 = (T[0] * p[2] + T[1] * p[3]) + T[2], y2 = (T[3] * p[2] + T[4] * p[3]) + T[5];
         const float angle = atanf_glibc((y2 - y1) / (x2 - x1));  // getAngle, math.h:295-299
-        const int bin = closest_orientation(P.keys, P.m, angle);  // dt3cpu.cpp:144-148
+        const int bin = closest_orientation(s_keys, P.m, angle);  // dt3cpu.cpp:144-148
         float* d = L + 5 * i;
         d[0] = x1; d[1] = y1; d[2] = x2; d[3] = y2; d[4] = __int_as_float(bin);
         mnx = std_min(mnx, std_min(x1, x2)); mxx = std_max(mxx, std_max(x1, x2));
         mny = std_min(mny, std_min(y1, y2)); mxy = std_max(mxy, std_max(y1, y2));
     }
     mnx = wave_min_f(mnx); mny = wave_min_f(mny); mxx = wave_max_f(mxx); mxy = wave_max_f(mxy);
-    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): LDS writes of the wave are done (single wave owns L)
-    __builtin_amdgcn_wave_barrier();
 
     // ---- optimize<BatchOptimize / DefaultOptimize> for this candidate
     bool valid = true;
@@ -178,49 +309,17 @@ __global__ void __launch_bounds__(256) k_search(const SearchParams P) {
     long long best_k = 0;
     unsigned long long n_eval = 0;
     if (valid) {
-        const size_t W = (size_t)P.W, H = (size_t)P.H;
-        // initial score at translation (0,0), :36
-        float init = 0.f;
-        if (lane == 0) init = score_translation(P.vol, L, n_t, P.tx + 0.f, P.ty + 0.f, W, H);
-        init = __shfl(init, 0);
-        n_eval += 1;
-        best = init;
-        float back = init;  // scores.back(): NOT reset between the two directions (batchoptimize.cpp:73)
-        const long long B = P.optimizer == FDCM_BATCH_OPTIMIZE ? P.batch : 1;
-        for (int dir = 1; dir >= -1; dir -= 2) {
-            const long long lim = dir > 0 ? (long long)max_mul : (long long)min_mul;  // static_cast<long>
-            for (long long k0 = dir; dir > 0 ? k0 <= lim : k0 >= lim; k0 += dir * B) {
-                // batch = k0, k0+dir, ... limited by B entries and by lim
-                long long nb = dir > 0 ? (lim - k0 + 1) : (k0 - lim + 1);
-                if (nb > B) nb = B;
-                // first argmin and last element over the batch, in chunks of 64 lanes
-                float bmin = 0.f, blast = 0.f;
-                long long bmin_k = 0;
-                for (long long c0 = 0; c0 < nb; c0 += 64) {
-                    const long long kk = k0 + dir * (c0 + lane);
-                    const bool act = (c0 + lane) < nb;
-                    float sc = f_inf();
-                    if (act) {
-                        const float trx = (float)kk * savx, try_ = (float)kk * savy;  // :58 / :81
-                        sc = score_translation(P.vol, L, n_t, P.tx + trx, P.ty + try_, W, H);
-                    }
-                    const int nact = (int)((nb - c0) < 64 ? (nb - c0) : 64);
-                    // std::min_element: first minimum
-                    float m = sc;
-                    for (int d = 32; d >= 1; d >>= 1) m = std_min(m, __shfl_xor(m, d));
-                    const unsigned long long eq = __ballot(act && sc == m);
-                    const int arg = eq ? (__ffsll((long long)eq) - 1) : 0;
-                    const float cmin = __shfl(sc, arg);
-                    if (c0 == 0 || cmin < bmin) { bmin = cmin; bmin_k = k0 + dir * (c0 + arg); }
-                    blast = __shfl(sc, nact - 1);
-                }
-                n_eval += (unsigned long long)nb;
-                if (bmin > back) break;                 // :65 / :88
-                back = bmin;                            // keep (translation, score)
-                if (bmin < best) { best = bmin; best_k = bmin_k; }  // first argmin over kept scores, :97
-                if (P.optimizer == FDCM_BATCH_OPTIMIZE && bmin < blast) break;  // :70 / :93
-            }
-        }
+        // Consecutive multipliers move every end point by one pixel along x (|savx| == 1) or along
+        // y; reading the copy whose fastest axis is that direction puts the ~20 translations of a
+        // round on one or two 128-byte lines per end point instead of one line each.
+        OptState o;
+        o.L = L; o.sc = sc; o.n_t = n_t; o.W = (size_t)P.W; o.H = (size_t)P.H; o.tx = P.tx; o.ty = P.ty;
+        o.savx = savx; o.savy = savy; o.lane = lane;
+        o.B = P.optimizer == FDCM_BATCH_OPTIMIZE ? P.batch : 1; o.WIN = P.win; o.batch_rule = P.optimizer == FDCM_BATCH_OPTIMIZE;
+        // static_cast<long>(max_mul / min_mul), batchoptimize.cpp:51,74
+        o.lim_p = (long long)max_mul; o.lim_n = (long long)min_mul;
+        if (f_abs(savx) == 1.0f) optimise<true>(P.vol_t, o, best, best_k, n_eval);
+        else optimise<false>(P.vol, o, best, best_k, n_eval);
     }
     if (lane == 0) {
         fdcm_match r;
@@ -240,35 +339,77 @@ __global__ void __launch_bounds__(256) k_search(const SearchParams P) {
     }
 }
 
-// Positional compaction of the valid records (defaultmatch.cpp:76-86): one block walks the
-// candidate list in chunks of 1024 with a running offset.
-__global__ void __launch_bounds__(1024) k_compact(const fdcm_match* __restrict__ records, const int* __restrict__ flags,
-                                                  long long n, fdcm_match* __restrict__ out,
-                                                  unsigned long long* __restrict__ counters) {
-    __shared__ int wsum[16];
-    __shared__ long long running;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) running = 0;
+// Positional compaction of the valid records (defaultmatch.cpp:76-86) in two small kernels:
+// per-chunk counts, then each chunk sums the counts before it, scans its flags and scatters.
+static constexpr int kChunk = 1024;
+__global__ void __launch_bounds__(256) k_chunk_counts(const int* __restrict__ flags, long long n, int* __restrict__ counts) {
+    __shared__ int part[4];
+    const long long c0 = (long long)blockIdx.x * kChunk;
+    int s = 0;
+    for (int i = threadIdx.x; i < kChunk; i += 256) s += (c0 + i < n) ? flags[c0 + i] : 0;
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
     __syncthreads();
-    for (long long c0 = 0; c0 < n; c0 += 1024) {
-        const long long i = c0 + tid;
-        const int f = i < n ? flags[i] : 0;
-        int incl = f;
-        for (int d = 1; d < 64; d <<= 1) {
-            const int o = __shfl_up(incl, d);
-            if (lane >= d) incl += o;
-        }
-        if (lane == 63) wsum[wave] = incl;
-        __syncthreads();
-        int wbase = 0;
-        for (int w = 0; w < wave; ++w) wbase += wsum[w];
-        const long long base = running;
-        if (f) out[base + wbase + incl - 1] = records[i];
-        __syncthreads();
-        if (tid == 1023) running = base + wbase + incl;
-        __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+__global__ void __launch_bounds__(1024) k_scatter(const fdcm_match* __restrict__ records, const int* __restrict__ flags,
+                                                  long long n, const int* __restrict__ counts, int nchunks,
+                                                  fdcm_match* __restrict__ out, unsigned long long* __restrict__ counters) {
+    __shared__ long long wsum[16];
+    __shared__ long long chunk_base;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    long long s = 0;
+    for (int i = tid; i < (int)blockIdx.x; i += 1024) s += counts[i];
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
+    if (lane == 0) wsum[wave] = s;
+    __syncthreads();
+    if (tid == 0) {
+        long long b = 0;
+        for (int w = 0; w < 16; ++w) b += wsum[w];
+        chunk_base = b;
     }
-    if (tid == 0) counters[2] = (unsigned long long)running;
+    __syncthreads();
+    const long long i = (long long)blockIdx.x * kChunk + tid;
+    const int f = i < n ? flags[i] : 0;
+    int incl = f;
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(incl, d);
+        if (lane >= d) incl += o;
+    }
+    __syncthreads();
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    long long wbase = 0;
+    for (int w = 0; w < wave; ++w) wbase += wsum[w];
+    if (f) out[chunk_base + wbase + incl - 1] = records[i];
+    if ((int)blockIdx.x == nchunks - 1 && tid == 1023) counters[2] = (unsigned long long)(chunk_base + wbase + incl);
+}
+
+// [k][x][y] -> [k][y][x] through 64x64 LDS tiles (both sides coalesced).
+__global__ void __launch_bounds__(256) k_transpose(const float* __restrict__ src, float* __restrict__ dst, int W, int H) {
+    __shared__ float tile[64][65];
+    const size_t slice = (size_t)blockIdx.z * W * H;
+    const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int r = ty; r < 64; r += 4) {  // r = x inside the tile, tx = y
+        const int x = x0 + r, y = y0 + tx;
+        if (x < W && y < H) tile[r][tx] = src[slice + (size_t)x * H + y];
+    }
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4) {  // r = y inside the tile, tx = x
+        const int x = x0 + tx, y = y0 + r;
+        if (x < W && y < H) dst[slice + (size_t)y * W + x] = tile[tx][r];
+    }
+}
+
+static void ensure_transposed(fdcm_featuremap* fm) {
+    if (fm->vol_t_valid) return;
+    const size_t bytes = (size_t)fm->m * fm->W * fm->H * sizeof(float);
+    fm->vol_t.reserve(bytes);
+    const dim3 grid((unsigned)((fm->W + 63) / 64), (unsigned)((fm->H + 63) / 64), (unsigned)fm->m);
+    hipLaunchKernelGGL(k_transpose, grid, dim3(256), 0, fm->stream, fm->vol.as<float>(), fm->vol_t.as<float>(), (int)fm->W,
+                       (int)fm->H);
+    fm->vol_t_valid = true;
 }
 
 int64_t search_capacity(const fdcm_templates* t, int64_t n_scene, int64_t maxT, int64_t maxS) {
@@ -309,9 +450,12 @@ void run_search(fdcm_featuremap* fm, const fdcm_templates* t, const float* scene
     std::sort(sidx.begin(), sidx.end(), [&slen](long const i1, long const i2) { return slen[i1] > slen[i2]; });
     // candidate offsets per template
     std::vector<long long> coff((size_t)t->T + 1, 0);
+    int64_t cpt_max = 0;
     for (int64_t i = 0; i < t->T; ++i) {
         const int64_t nt = t->offsets[i + 1] - t->offsets[i];
-        coff[i + 1] = coff[i] + 2 * std::min<int64_t>(nt, maxT) * window;
+        const int64_t c = 2 * std::min<int64_t>(nt, maxT) * window;
+        coff[i + 1] = coff[i] + c;
+        cpt_max = std::max(cpt_max, c);
     }
     const long long ncand = coff[t->T];
     fm->last_search.candidates = ncand;
@@ -329,13 +473,16 @@ void run_search(fdcm_featuremap* fm, const fdcm_templates* t, const float* scene
     for (int i = 0; i < n_s; ++i) { hl[i] = slen[sidx[i]]; hi[i] = (int)sidx[i]; }
     std::memcpy(hs + o_coff, coff.data(), coff.size() * 8);
     FDCM_HIP(hipMemcpyAsync(fm->s_scene.p, hs, blob, hipMemcpyHostToDevice, st));
+    const int nchunks = (int)((ncand + kChunk - 1) / kChunk);
     fm->s_records.reserve((size_t)ncand * sizeof(fdcm_match));
-    fm->s_flags.reserve((size_t)ncand * sizeof(int));
+    fm->s_flags.reserve((size_t)ncand * sizeof(int) + (size_t)nchunks * sizeof(int));
     fm->s_counter.reserve(64);
     FDCM_HIP(hipMemsetAsync(fm->s_counter.p, 0, 64, st));
     // keys live at the end of the build plan blob; for adopted volumes they are uploaded there too
     SearchParams P{};
     P.vol = fm->vol.as<float>();
+    ensure_transposed(fm);
+    P.vol_t = fm->vol_t.as<float>();
     P.keys = (const float*)((const char*)fm->plan.p + fm->off_keys);
     P.W = (int)fm->W; P.H = (int)fm->H; P.m = (int)fm->m; P.tx = fm->tx; P.ty = fm->ty;
     P.tlines = t->d_lines.as<float>();
@@ -349,26 +496,37 @@ void run_search(fdcm_featuremap* fm, const fdcm_templates* t, const float* scene
     P.s_sorted_idx = (const int*)(ds + o_idx);
     P.n_s = n_s;
     P.maxT = (int)maxT; P.maxS = (int)maxS; P.window = window;
-    P.optimizer = optimizer; P.batch = batch < 1 ? 1 : batch; P.base = base;
+    P.optimizer = optimizer;
+    const int64_t B = optimizer == FDCM_BATCH_OPTIMIZE ? std::max<int64_t>(1, batch) : 1;
+    if (B > 4096) throw std::string("batch_size above 4096 is not supported");
+    P.batch = (int)B;
+    // multipliers scored per direction and round: whole batches, 15 at most when they fit one round
+    P.win = B <= 15 ? (int)((15 / B) * B) : (int)B;
+    P.base = base;
     P.cand_offsets = (const long long*)(ds + o_coff);
-    P.ncand = ncand;
+    P.bpt = (int)((cpt_max + kWavesPerBlock - 1) / kWavesPerBlock);
     P.lds_lines = (int)std::max<int64_t>(1, t->max_lines);
     P.records = fm->s_records.as<fdcm_match>();
     P.flags = fm->s_flags.as<int>();
     P.counters = fm->s_counter.as<unsigned long long>();
-    const size_t lds = (size_t)4 * P.lds_lines * 5 * sizeof(float);
-    if (lds > 160 * 1024) throw std::string("template with too many lines for the per-wave LDS area");
+    const size_t lds_floats = (size_t)P.m + 6 * (size_t)n_s + 6 * (size_t)P.lds_lines +
+                              (size_t)kWavesPerBlock * P.lds_lines * 5 + (size_t)kWavesPerBlock * (2 * P.win + 1);
+    const size_t lds = lds_floats * sizeof(float);
+    if (lds > 160 * 1024) throw std::string("scene/template too large for the search kernel's LDS staging");
     if (lds > 64 * 1024)
         FDCM_HIP(hipFuncSetAttribute((const void*)k_search, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t* ev = fm->timing.ev;
     FDCM_HIP(hipEventRecord(ev[6], st));
-    hipLaunchKernelGGL(k_search, dim3((unsigned)((ncand + 3) / 4)), dim3(256), lds, st, P);
+    hipLaunchKernelGGL(k_search, dim3((unsigned)((size_t)t->T * P.bpt)), dim3(256), lds, st, P);
     fdcm_match* dst = out_device;
     if (!dst) {
         fm->s_out.reserve((size_t)ncand * sizeof(fdcm_match));
         dst = fm->s_out.as<fdcm_match>();
     }
-    hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, st, P.records, P.flags, ncand, dst, P.counters);
+    int* d_counts = P.flags + ncand;
+    hipLaunchKernelGGL(k_chunk_counts, dim3((unsigned)nchunks), dim3(256), 0, st, P.flags, ncand, d_counts);
+    hipLaunchKernelGGL(k_scatter, dim3((unsigned)nchunks), dim3(1024), 0, st, P.records, P.flags, ncand, d_counts, nchunks,
+                       dst, P.counters);
     FDCM_HIP(hipEventRecord(ev[7], st));
     FDCM_HIP(hipGetLastError());
     unsigned long long hc[3] = {0, 0, 0};
