@@ -25,9 +25,11 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0
-# algorithmic bytes per build stage, in units of V = 4*m*W*H (7V in total)
-STAGE_BYTES_V = {"pass1_ms": 1.0, "pass2_ms": 2.0, "propagate_ms": 2.0, "integral_ms": 2.0}
-STAGE_KERNEL = {"pass1_ms": "k_pass1", "pass2_ms": "k_pass2_l2", "propagate_ms": "k_propagate",
+# Algorithmic bytes per build stage, in units of V = 4*m*W*H (7V in total):
+# distance transform = pass 1 writes V + pass 2 reads V and writes V (one fused kernel here, which
+# actually moves ~V + V/16); propagation reads V and writes V; line integral reads V and writes V.
+STAGE_BYTES_V = {"pass2_ms": 3.0, "propagate_ms": 2.0, "integral_ms": 2.0}
+STAGE_KERNEL = {"pass2_ms": "k_pass2_l2 (passes 1+2 of the distance transform)", "propagate_ms": "k_propagate",
                 "integral_ms": "k_integral"}
 
 

@@ -32,10 +32,10 @@ def gather_matches(local_records, device, group=None, dst=0):
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     n_local = local_records.numel() // RECORD_BYTES
-    counts = torch.zeros(world, dtype=torch.int64, device=device)
     mine = torch.tensor([n_local], dtype=torch.int64, device=device)
-    dist.all_gather_into_tensor(counts, mine, group=group)
-    counts_h = counts.cpu().tolist()
+    counts = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(counts, mine, group=group)
+    counts_h = [int(c.item()) for c in counts]
     cap = max(1, max(counts_h)) * RECORD_BYTES
     send = torch.zeros(cap, dtype=torch.uint8, device=device)
     send[: n_local * RECORD_BYTES] = local_records[: n_local * RECORD_BYTES]

@@ -195,7 +195,7 @@ def clip_lines(lines, xmin, xmax, ymin, ymax):
 
 def draw_lines(img, lines, color):
     """img: (H, W) array; returns a new (H, W) float32 array."""
-    a = np.ascontiguousarray(np.asarray(img, dtype=np.float32).T)  # [x][y]
+    a = np.array(np.asarray(img, dtype=np.float32).T, dtype=np.float32, order="C", copy=True)  # [x][y]
     s = as_lines(lines)
     lib().fdcmo_draw_lines(_fp(a), a.shape[1], a.shape[0], _fp(s), s.shape[0], color)
     return a.T
@@ -209,13 +209,13 @@ def distance_transform(lines, W, H, distance):
 
 
 def column_pass_l2(img):
-    a = np.ascontiguousarray(np.asarray(img, dtype=np.float32).T)
+    a = np.array(np.asarray(img, dtype=np.float32).T, dtype=np.float32, order="C", copy=True)
     lib().fdcmo_column_pass_l2(_fp(a), a.shape[1], a.shape[0])
     return a.T
 
 
 def line_integral(img, angle):
-    a = np.ascontiguousarray(np.asarray(img, dtype=np.float32).T)
+    a = np.array(np.asarray(img, dtype=np.float32).T, dtype=np.float32, order="C", copy=True)
     lib().fdcmo_line_integral(_fp(a), a.shape[1], a.shape[0], np.float32(angle))
     return a.T
 

@@ -67,7 +67,3 @@ def test_lineio_roundtrip_and_assets(tmp_path):
     assert back.shape == (4, 100) and np.array_equal(back, lines)
     with pytest.raises(RuntimeError):
         lineio.read(str(tmp_path / "missing.lines"))
-    golden = os.path.join(ROOT, "tests", "golden", "obj_04_scene_0.scene")
-    if os.path.exists(golden):
-        s = lineio.read(golden)
-        assert s.shape == (4, 646)

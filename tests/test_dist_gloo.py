@@ -1,0 +1,71 @@
+"""World-size-2 test of the template sharding + match gather on CPU (gloo backend).
+
+The per-rank search is stood in by the CPU oracle on the rank's contiguous template shard (with
+tmpl_idx offset by the shard's first template, like fdcm_search's tmpl_index_base); what is under
+test is openfdcm_amd.dist: shard ranges, the count exchange, the padded gather and that
+concatenating shards in rank order reproduces the single-process positional match list.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from helpers import ROOT  # noqa: F401
+from openfdcm_amd import synthetic
+from openfdcm_amd._capi import MATCH_DTYPE
+from openfdcm_amd.dist import RECORD_BYTES, gather_matches, shard_range
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n_templates, out_path):
+    from oracle import oracle as O
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        S = 128
+        scene = synthetic.scene(S, 30, 5)
+        tmpls = synthetic.templates(n_templates, 9, S, 6)
+        fm = O.build(scene, depth=12, coeff=5.0, padding=1.0)  # every rank builds the DT3 volume itself
+        b, e = shard_range(len(tmpls), rank, world)
+        local = O.search(fm, tmpls[b:e], scene, 3, 3, kind=O.BATCH_OPTIMIZE, batch=10).astype(MATCH_DTYPE)
+        local["tmpl_idx"] += b
+        buf = torch.from_numpy(local.view(np.uint8).copy()) if len(local) else torch.zeros(0, dtype=torch.uint8)
+        res = gather_matches(buf, torch.device("cpu"))
+        if rank == 0:
+            full = O.search(fm, tmpls, scene, 3, 3, kind=O.BATCH_OPTIMIZE, batch=10)
+            assert res is not None and len(res) == len(full)
+            assert np.array_equal(res["tmpl_idx"], full["tmpl_idx"])
+            assert np.array_equal(res["score"], full["score"])
+            assert np.array_equal(res["transform"], full["transform"])
+            np.save(out_path, np.array([len(res)]))
+        else:
+            assert res is None
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_templates", [7, 2, 1])
+def test_sharded_gather_world2(tmp_path, n_templates):
+    out = str(tmp_path / "n.npy")
+    mp.spawn(_worker, args=(2, _free_port(), n_templates, out), nprocs=2, join=True)
+    assert np.load(out)[0] > 0
+
+
+def test_shard_ranges_cover_and_are_contiguous():
+    for n in (0, 1, 7, 1000, 16001):
+        for w in (1, 2, 3, 8):
+            r = [shard_range(n, i, w) for i in range(w)]
+            assert r[0][0] == 0 and r[-1][1] == n
+            assert all(r[i][1] == r[i + 1][0] for i in range(w - 1))
+            assert max(e - b for b, e in r) - min(e - b for b, e in r) <= 1
+    assert RECORD_BYTES == 32
