@@ -425,6 +425,50 @@ __global__ void k_propagate(float* __restrict__ vol, size_t npix, int m, const P
         for (int j = 0; j < m; ++j) vol[(size_t)j * npix + p] = S[j * bd + tid];
 }
 
+// Register-resident variant for the common depths: the ring indices of propagateOrientation's
+// 4M steps (dt3cpu.cpp:88-89) are compile-time constants, so the pixel's M-vector stays in VGPRs
+// and the kernel is a pure stream (read V, write V) at full occupancy.
+template <int M>
+__global__ void __launch_bounds__(256) k_propagate_reg(float* __restrict__ vol, size_t npix,
+                                                       const PropStep* __restrict__ steps, int apply_sqrt) {
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npix) return;
+    // One buffer descriptor per slice (scalar registers) + one 32-bit lane byte offset: addresses
+    // cost no vector registers, so the M values are the kernel's whole register footprint.
+    const int boff = (int)((unsigned)p * 4u);  // npix < 2^30
+    const unsigned slice_bytes = (unsigned)(npix * 4u);
+    float S[M];
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(vol + (size_t)j * npix, 0, slice_bytes, 0x00020000);
+        S[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, boff, 0, 0));
+    }
+    if (apply_sqrt) {
+#pragma unroll
+        for (int j = 0; j < M; ++j) S[j] = sqrtf(S[j]);
+    }
+    constexpr int FWD = (3 * M + 1) / 2;  // ceil(1.5 M)
+    constexpr int BWD = (3 * M) / 2;      // floor(1.5 M)
+    int s = 0;
+#pragma unroll
+    for (int c = 0; c < FWD; ++c, ++s) {  // propagate(0, ceil(1.5 m), +1)
+        constexpr int dummy = 0; (void)dummy;
+        const int c1 = (M + ((c - 1) % M)) % M, c2 = (M + (c % M)) % M;
+        S[c2] = std_min(S[c2], S[c1] + steps[s].w);
+    }
+#pragma unroll
+    for (int i = 0; i < M + BWD; ++i, ++s) {  // propagate(m, -floor(1.5 m), -1): c = M - i
+        const int c = M - i;
+        const int c1 = (M + ((c + 1) % M)) % M, c2 = (M + (c % M)) % M;
+        S[c2] = std_min(S[c2], S[c1] + steps[s].w);
+    }
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(vol + (size_t)j * npix, 0, slice_bytes, 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(S[j]), rs, boff, 0, 0);
+    }
+}
+
 // ------------------------------------------------------------------------------------------ K4
 // lineIntegral (imgproc.h:38-84).  The reference adds the previous (already integrated) line,
 // shifted by dy_i = round(i r) - round((i-1) r), into the current one; the shifts telescope, so
@@ -440,7 +484,7 @@ __global__ void __launch_bounds__(256) k_integral(float* __restrict__ vol, int W
     constexpr int U = 8, NB = 6;
     const int k = blockIdx.y;
     const IntegralDesc d = desc[k];
-    if (d.mode == 0) return;
+    if (d.mode != 1) return;  // steep slices: k_integral_steep
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane >= LP) return;
     float* img = vol + (size_t)k * W * H;
@@ -484,6 +528,182 @@ __global__ void __launch_bounds__(256) k_integral(float* __restrict__ vol, int W
                 }
             }
             fetch(b, i0 + (NB + b) * U);
+        }
+    }
+}
+
+// Chain offsets round(float(i) * r) of every slice (imgproc.h:54-55,70-71), one table row per slice.
+__global__ void k_offsets(const IntegralDesc* __restrict__ desc, int* __restrict__ offtab, int steps) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
+    if (i < steps) offtab[(size_t)k * steps + i] = (int)roundf((float)i * desc[k].r);
+}
+
+// Shallow slices (mode 1: the sweep runs along x, the 64 chains of a wave are 64 consecutive y).
+// At step i the wave's elements are one contiguous 256-byte run whose start is wave-uniform, so the
+// common case is: scalar address arithmetic, one buffer load, one add, one buffer store per step.
+// A batch of 8 steps is classified (uniformly) as outside the image, fully inside, or on the border
+// (per-lane clamping); 48 loads are kept in flight per lane.
+struct ShBuf {
+    float v[8];
+    int xo[8];  // border batches: in-row index or -1
+    int type;   // 0 outside, 1 inside, 2 border (wave-uniform)
+};
+
+__device__ __forceinline__ void sh_fetch(ShBuf& B, __amdgpu_buffer_rsrc_t rs, const int* __restrict__ off, int i0,
+                                         int steps, int span, int H, int start, int s, int c0, int lane) {
+    if (i0 >= steps) { B.type = 0; return; }
+    const int ilast = min(i0 + 7, steps - 1);
+    const int oa = off[i0], ob = off[ilast];
+    const int omin = min(oa, ob), omax = max(oa, ob);
+    if (c0 + 63 + omax < 0 || c0 + omin >= span) { B.type = 0; return; }
+    if (c0 + omin >= 0 && c0 + 63 + omax < span && i0 + 8 <= steps) {
+        B.type = 1;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int soff = ((start + (i0 + j) * s) * H + c0 + off[i0 + j]) * 4;
+            B.v[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, lane * 4, soff, 0));
+        }
+        return;
+    }
+    B.type = 2;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int i = i0 + j;
+        const int x = c0 + lane + off[min(i, steps - 1)];
+        const bool ok = i < steps && x >= 0 && x < span;
+        B.xo[j] = ok ? x : -1;
+        const int soff = (start + min(i, steps - 1) * s) * H * 4;
+        const float t = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, max(0, min(x, span - 1)) * 4, soff, 0));
+        B.v[j] = ok ? t : 0.f;
+    }
+}
+
+__device__ __forceinline__ void sh_consume(const ShBuf& B, float& acc, __amdgpu_buffer_rsrc_t rs,
+                                           const int* __restrict__ off, int i0, int steps, int H, int start, int s,
+                                           int c0, int lane) {
+    if (B.type == 0) return;
+    if (B.type == 1) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            acc = B.v[j] + acc;  // 0 + v == v exactly before the chain starts (v >= +0)
+            const int soff = ((start + (i0 + j) * s) * H + c0 + off[i0 + j]) * 4;
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc), rs, lane * 4, soff, 0);
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        acc = B.v[j] + acc;
+        if (B.xo[j] >= 0) {
+            const int soff = (start + min(i0 + j, steps - 1) * s) * H * 4;
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc), rs, B.xo[j] * 4, soff, 0);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_integral_shallow(float* __restrict__ vol, int W, int H,
+                                                          const IntegralDesc* __restrict__ desc,
+                                                          const int* __restrict__ offtab) {
+    constexpr int NB = 6;
+    const int k = blockIdx.y;
+    const IntegralDesc d = desc[k];
+    if (d.mode != 1) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int steps = W, span = H;
+    const int* off = offtab + (size_t)k * steps;
+    const int last_off = off[steps - 1];
+    const int cmin = -max(0, last_off), cmax = span - 1 - min(0, last_off);
+    const int c0 = cmin + ((int)blockIdx.x * 4 + wave) * 64;
+    if (c0 > cmax) return;
+    const int start = d.s < 0 ? steps - 1 : 0;
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc(vol + (size_t)k * W * H, 0, (unsigned)((size_t)W * H * 4), 0x00020000);
+    float acc = 0.f;
+    ShBuf B[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) sh_fetch(B[b], rs, off, b * 8, steps, span, H, start, d.s, c0, lane);
+    for (int i0 = 0; i0 < steps; i0 += NB * 8) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            sh_consume(B[b], acc, rs, off, i0 + b * 8, steps, H, start, d.s, c0, lane);
+            sh_fetch(B[b], rs, off, i0 + (NB + b) * 8, steps, span, H, start, d.s, c0, lane);
+        }
+    }
+}
+
+// Steep slices (mode 2: the sweep runs along y, chains run across x) would read and write one
+// 4-byte element per 4 KiB-strided lane in the y-fastest layout.  They go through LDS tiles
+// instead: a block owns XC neighbouring chains, loads [XC + 32 columns] x [32 sweep steps] with
+// 128-byte segments along y, wave 0 runs the 64 sequential sums on the tile, and the tile is
+// stored back the same way.  The next tile's loads are in flight while the current one is
+// summed and stored.  Only elements that belong to the block's own chains are written.
+template <int XC>
+__global__ void __launch_bounds__(256) k_integral_steep(float* __restrict__ vol, int W, int H,
+                                                        const IntegralDesc* __restrict__ desc) {
+    constexpr int TS = 32, TW = XC + TS, PASSES = TW / 8;
+    __shared__ float tile[2][TW][TS + 1];
+    const int k = blockIdx.y;
+    const IntegralDesc d = desc[k];
+    if (d.mode != 2) return;
+    float* img = vol + (size_t)k * W * H;
+    const int steps = H, span = W;
+    const int last_off = (int)roundf((float)(steps - 1) * d.r);
+    const int cmin = -max(0, last_off), cmax = span - 1 - min(0, last_off);
+    const int c0 = cmin + (int)blockIdx.x * XC;
+    if (c0 > cmax) return;
+    const int c_hi = min(c0 + XC - 1, cmax);
+    const int start = d.s < 0 ? steps - 1 : 0;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int prow = tid & 31, pcol = tid >> 5;  // load/store mapping: 8 columns x 32 rows per pass
+    const int ntiles = (steps + TS - 1) / TS;
+    auto off_at = [&](int i) { return (int)roundf((float)i * d.r); };  // chain offset at step i (imgproc.h:70-71)
+    auto xbase = [&](int t) { return c0 + min(off_at(t * TS), off_at(min(t * TS + TS - 1, steps - 1))); };
+    float regs[PASSES];
+    auto load_tile = [&](int t) {
+        const int i = t * TS + prow, y = start + i * d.s, xb = xbase(t);
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) {
+            const int x = xb + p * 8 + pcol;
+            regs[p] = (i < steps && x >= 0 && x < W) ? img[(size_t)x * H + y] : 0.f;
+        }
+    };
+    float acc = 0.f;
+    load_tile(0);
+    for (int t = 0; t < ntiles; ++t) {
+        const int buf = t & 1, i0 = t * TS, xb = xbase(t);
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) tile[buf][p * 8 + pcol][prow] = regs[p];
+        __syncthreads();
+        if (t + 1 < ntiles) load_tile(t + 1);
+        if (wave == 0) {
+            const int c = c0 + lane;
+            const int my_off = off_at(i0 + (lane & 31));  // lane j < 32 holds the offset of step i0 + j
+            // all 32 reads are issued before the dependent chain of adds (they never alias: one
+            // element per step), so the chain costs 32 adds, not 32 LDS round trips
+            float v[TS];
+            int xi[TS];
+#pragma unroll
+            for (int ii = 0; ii < TS; ++ii) {
+                const int x = c + __builtin_amdgcn_readlane(my_off, ii);
+                const bool ok = i0 + ii < steps && c <= c_hi && x >= 0 && x < W;
+                xi[ii] = ok ? x - xb : -1;
+                v[ii] = ok ? tile[buf][x - xb][ii] : 0.f;
+            }
+#pragma unroll
+            for (int ii = 0; ii < TS; ++ii) {
+                acc = v[ii] + acc;  // 0 + v == v exactly before the chain starts (v >= +0)
+                if (xi[ii] >= 0) tile[buf][xi[ii]][ii] = acc;
+            }
+        }
+        __syncthreads();
+        {
+            const int i = i0 + prow, y = start + i * d.s;
+            const int o = off_at(i);
+#pragma unroll
+            for (int p = 0; p < PASSES; ++p) {
+                const int x = xb + p * 8 + pcol, c = x - o;
+                if (i < steps && x >= 0 && x < W && c >= c0 && c <= c_hi) img[(size_t)x * H + y] = tile[buf][p * 8 + pcol][prow];
+            }
         }
     }
 }
@@ -574,25 +794,36 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after) {
     FDCM_HIP(hipEventRecord(ev[3], st));
     const bool want_sqrt = fm->distance == FDCM_L2;
     if (stop_after >= 2) {
-        int bd = 256;
-        while (bd > 64 && (size_t)m * bd * sizeof(float) > 64 * 1024) bd >>= 1;
-        const size_t lds = (size_t)m * bd * sizeof(float);
-        if (lds > 64 * 1024)
-            FDCM_HIP(hipFuncSetAttribute((const void*)k_propagate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_propagate, dim3((unsigned)((npix + bd - 1) / bd)), dim3(bd), lds, st, vol, npix, m, d_prop,
-                           (int)fm->n_prop, want_sqrt ? 1 : 0);
+        const unsigned pblocks = (unsigned)((npix + 255) / 256);
+        const int sq = want_sqrt ? 1 : 0;
+        if (m == 30) hipLaunchKernelGGL(k_propagate_reg<30>, dim3(pblocks), dim3(256), 0, st, vol, npix, d_prop, sq);
+        else if (m == 60) hipLaunchKernelGGL(k_propagate_reg<60>, dim3(pblocks), dim3(256), 0, st, vol, npix, d_prop, sq);
+        else if (m == 90) hipLaunchKernelGGL(k_propagate_reg<90>, dim3(pblocks), dim3(256), 0, st, vol, npix, d_prop, sq);
+        else if (m == 120) hipLaunchKernelGGL(k_propagate_reg<120>, dim3(pblocks), dim3(256), 0, st, vol, npix, d_prop, sq);
+        else if (m == 180) hipLaunchKernelGGL(k_propagate_reg<180>, dim3(pblocks), dim3(256), 0, st, vol, npix, d_prop, sq);
+        else {
+            int bd = 256;
+            while (bd > 64 && (size_t)m * bd * sizeof(float) > 64 * 1024) bd >>= 1;
+            const size_t lds = (size_t)m * bd * sizeof(float);
+            if (lds > 64 * 1024)
+                FDCM_HIP(hipFuncSetAttribute((const void*)k_propagate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(k_propagate, dim3((unsigned)((npix + bd - 1) / bd)), dim3(bd), lds, st, vol, npix, m, d_prop,
+                               (int)fm->n_prop, sq);
+        }
     } else if (want_sqrt) {
         hipLaunchKernelGGL(k_sqrt, dim3((unsigned)((nvox + 255) / 256)), dim3(256), 0, st, vol, nvox);
     }
     FDCM_HIP(hipEventRecord(ev[4], st));
     if (stop_after >= 3) {
         const int chains = 2 * (W > H ? W : H);
-        int LP = 64;  // chains per wave: keep >= 4096 waves when the volume is small
-        while (LP > 16 && (long)m * ((chains + LP - 1) / LP) < 4096) LP >>= 1;
-        const dim3 grid((unsigned)((chains + 4 * LP - 1) / (4 * LP)), (unsigned)m);
-        if (LP == 64) hipLaunchKernelGGL(k_integral<64>, grid, dim3(256), 0, st, vol, W, H, d_int);
-        else if (LP == 32) hipLaunchKernelGGL(k_integral<32>, grid, dim3(256), 0, st, vol, W, H, d_int);
-        else hipLaunchKernelGGL(k_integral<16>, grid, dim3(256), 0, st, vol, W, H, d_int);
+        const int steps = W > H ? W : H;
+        fm->offtab.reserve((size_t)m * steps * sizeof(int));
+        int* d_off = fm->offtab.as<int>();
+        hipLaunchKernelGGL(k_offsets, dim3((unsigned)((steps + 255) / 256), (unsigned)m), dim3(256), 0, st, d_int, d_off, steps);
+        hipLaunchKernelGGL(k_integral_shallow, dim3((unsigned)((chains + 255) / 256), (unsigned)m), dim3(256), 0, st, vol, W, H,
+                           d_int, d_off);
+        hipLaunchKernelGGL(k_integral_steep<64>, dim3((unsigned)((chains + 63) / 64), (unsigned)m), dim3(256), 0, st, vol, W, H,
+                           d_int);
     }
     FDCM_HIP(hipEventRecord(ev[5], st));
     FDCM_HIP(hipGetLastError());

@@ -48,7 +48,7 @@ static void upload_keys_only(fdcm_featuremap* fm) {
 static void destroy(fdcm_featuremap* fm) {
     if (!fm) return;
     (void)hipSetDevice(fm->device);
-    fm->vol.release(); fm->vol_t.release(); fm->bitmap.release(); fm->coldesc.release(); fm->stack.release(); fm->plan.release(); fm->stage.release();
+    fm->vol.release(); fm->vol_t.release(); fm->bitmap.release(); fm->coldesc.release(); fm->offtab.release(); fm->stack.release(); fm->plan.release(); fm->stage.release();
     fm->s_scene.release(); fm->s_records.release(); fm->s_flags.release(); fm->s_out.release();
     fm->s_counter.release(); fm->s_stage.release();
     if (fm->timing.created)

@@ -104,6 +104,7 @@ struct fdcm_featuremap {
     bool vol_t_valid = false;
     fdcm::DevBuf bitmap;   // m*W*ceil(H/64) uint64 seed bits along y
     fdcm::DevBuf coldesc;  // m*ceil(H/64)*W column-chunk descriptors (16 B)
+    fdcm::DevBuf offtab;   // m * max(W,H) chain offsets of the line integral
     fdcm::DevBuf stack;    // K2 scratch: per row a (v, f, z) stack of W entries
     fdcm::DevBuf plan;     // RasterLine[] | PropStep[] | IntegralDesc[] | keys[]
     fdcm::PinnedBuf stage; // host staging for the plan
