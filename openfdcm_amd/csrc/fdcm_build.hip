@@ -13,6 +13,7 @@
 //   K4 k_integral   directional prefix sum per slice, one sequential chain per thread    read V, write V
 // Compiled with -ffp-contract=off; divide and sqrt are the correctly rounded forms.
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 
 #include "fdcm_internal.h"
@@ -736,6 +737,7 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after) {
     const long nchunks = (long)m * HW64;  // (slice, 64-row chunk) pairs
     int R = 64;                            // rows per wave of the L2 sweep: keep >= 2048 waves in flight
     while (R > 16 && nchunks * (64 / R) < 2048) R >>= 1;
+    if (const char* e = getenv("FDCM_K2_ROWS")) R = atoi(e);  // tuning override (16, 32 or 64)
     const long nwaves = fm->distance == FDCM_L1 ? nchunks : nchunks * (64 / R);
     fm->coldesc.reserve((size_t)ncols * HW64 * sizeof(ColDesc));
     if (fm->distance != FDCM_L1) fm->stack.reserve((size_t)W * nwaves * R * 12);
