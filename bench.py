@@ -29,8 +29,21 @@ HBM_PEAK_GBS = 8000.0
 # distance transform = pass 1 writes V + pass 2 reads V and writes V (one fused kernel here, which
 # actually moves ~V + V/16); propagation reads V and writes V; line integral reads V and writes V.
 STAGE_BYTES_V = {"pass2_ms": 3.0, "propagate_ms": 2.0, "integral_ms": 2.0}
-STAGE_KERNEL = {"pass2_ms": "k_pass2_l2 (passes 1+2 of the distance transform)", "propagate_ms": "k_propagate",
-                "integral_ms": "k_integral"}
+STAGE_KERNEL = {"pass2_ms": "k_pass2_l2", "propagate_ms": "k_propagate_reg", "integral_ms": "k_integral_shallow+steep"}
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC summary (profiles/*pmc_traffic*.json:
+    separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, FETCH doubled per
+    MI355X_MICROARCH.md).  Counters cannot be read from inside the timed run, hence the file."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json")))
+    if not files:
+        return None
+    ks = json.load(open(files[-1]))["kernels"]
+    tot = [v["hbm_bytes_per_launch"] for k, v in ks.items() if any(part in k for part in kernel.split("+"))
+           or kernel.split("+")[0].replace("shallow", "") in k]
+    return float(sum(tot)) if tot else None
 
 
 def cpu_baseline(cfg, scene, tmpls, sample_templates):
@@ -145,7 +158,7 @@ def main():
             "search_matches_per_s": n_matches / (search_total_ms / K * 1e-3) if search_total_ms else None,
             "stage_ms": {k: round(v, 4) for k, v in avg.items()},
             "roofline": {"bound": "hbm", "kernel": STAGE_KERNEL[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(STAGE_KERNEL[dom]),
                          "algorithmic_bytes_per_launch": STAGE_BYTES_V[dom] * V, "avg_launch_ms": avg[dom]},
         }
         if args.cpu_sample > 0:

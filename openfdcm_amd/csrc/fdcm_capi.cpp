@@ -49,7 +49,7 @@ static void destroy(fdcm_featuremap* fm) {
     if (!fm) return;
     (void)hipSetDevice(fm->device);
     fm->vol.release(); fm->vol_t.release(); fm->bitmap.release(); fm->coldesc.release(); fm->offtab.release(); fm->stack.release(); fm->plan.release(); fm->stage.release();
-    fm->s_scene.release(); fm->s_records.release(); fm->s_flags.release(); fm->s_out.release();
+    fm->s_scene.release(); fm->s_pairs.release(); fm->s_records.release(); fm->s_flags.release(); fm->s_out.release();
     fm->s_counter.release(); fm->s_stage.release();
     if (fm->timing.created)
         for (auto& e : fm->timing.ev) (void)hipEventDestroy(e);

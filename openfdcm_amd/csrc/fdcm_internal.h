@@ -112,6 +112,7 @@ struct fdcm_featuremap {
     int64_t n_raster = 0, n_prop = 0;
     // search workspaces
     fdcm::DevBuf s_scene;   // scene lines + sorted lengths + sorted idx
+    fdcm::DevBuf s_pairs;   // (template line, scene line) per search combination
     fdcm::DevBuf s_records; // per-candidate result records
     fdcm::DevBuf s_flags;   // per-candidate valid flag + scan scratch
     fdcm::DevBuf s_out;     // compacted matches

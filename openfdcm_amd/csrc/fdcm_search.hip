@@ -51,11 +51,14 @@ struct SearchParams {
     int base;
     // candidates
     const long long* cand_offsets;  // T+1
+    const int2* pairs;              // per template, per (j, wi): {template line, scene line}
+    int pairs_stride;               // maxT * window
     int bpt;                        // workgroups per template
     int lds_lines;                  // capacity (lines) of the LDS template / aligned-line areas
     // outputs
     fdcm_match* records;
     int* flags;
+    int* evals;
     unsigned long long* counters;  // [0] translations evaluated by the rule, [1] volume reads, [2] matches
 };
 
@@ -120,7 +123,7 @@ __device__ __forceinline__ float pair_score(const float* __restrict__ vol, const
     float res = 0.f;
     if (aligned >= 8) {
 #pragma unroll
-        for (int l = 0; l < 4; ++l) acc[l] = acc[l] + __shfl_xor(acc[l], 1);  // h = 0: p0 + p1
+        for (int l = 0; l < 4; ++l) acc[l] = acc[l] + __shfl_xor(acc[l], 32);  // h = 0: p0 + p1
     }
     if (active && h == 0) {
         if (aligned) {
@@ -153,7 +156,7 @@ struct OptState {
 template <bool XF>
 __device__ __forceinline__ void score_range(const float* __restrict__ vol, const OptState& o, int dir, long long k_from,
                                             int cnt, int dst, bool with_zero) {
-    const int h = o.lane & 1, slot = o.lane >> 1;
+    const int h = o.lane >> 5, slot = o.lane & 31;  // neighbouring lanes = neighbouring translations
     const int total = cnt + (with_zero ? 1 : 0);
     for (int s0 = 0; s0 < total; s0 += 32) {
         const int idx = s0 + slot - (with_zero ? 1 : 0);  // -1 = the zero translation
@@ -172,7 +175,7 @@ template <bool XF>
 __device__ __forceinline__ void optimise(const float* __restrict__ vol, const OptState& o, float& best, long long& best_k,
                                          unsigned long long& n_eval) {
     const int WIN = o.WIN, B = o.B;
-    const int h = o.lane & 1, slot = o.lane >> 1;
+    const int h = o.lane >> 5, slot = o.lane & 31;  // neighbouring lanes = neighbouring translations
     // ---- round 1: translation 0 and the first WIN multipliers of both directions
     const int have_p = (int)min<long long>(WIN, o.lim_p >= 1 ? o.lim_p : 0);
     const int have_n = (int)min<long long>(WIN, o.lim_n <= -1 ? -o.lim_n : 0);
@@ -230,6 +233,25 @@ __device__ __forceinline__ void optimise(const float* __restrict__ vol, const Op
     }
 }
 
+// establishSearchStrategy<DefaultSearch> (defaultsearch.cpp:38-46) for every (template, j-th longest
+// template line): binary search of its length among the scene lengths, centred window of scene lines.
+__global__ void k_pairs(const SearchParams P) {
+    const int gidx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int per = P.maxT;
+    if (gidx >= P.T * per) return;
+    const int t = gidx / per, j = gidx - t * per;
+    const long long l0 = P.toffsets[t];
+    const int n_t = (int)(P.toffsets[t + 1] - l0);
+    if (j >= n_t) return;
+    const int tl_local = P.tsorted[l0 + j];
+    const float tlen = P.tlengths[l0 + tl_local];
+    const int centre = binary_search_greater(P.s_sorted_len, P.n_s, tlen);
+    int rb, re;
+    centered_range(centre, P.n_s, P.maxS, rb, re);
+    int2* out = const_cast<int2*>(P.pairs) + (size_t)t * P.pairs_stride + (size_t)j * P.window;
+    for (int wi = 0; wi < P.window; ++wi) out[wi] = make_int2(tl_local, P.s_sorted_idx[rb + wi]);
+}
+
 __global__ void __launch_bounds__(256) k_search(const SearchParams P) {
     extern __shared__ float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -238,39 +260,22 @@ __global__ void __launch_bounds__(256) k_search(const SearchParams P) {
     const long long l0 = P.toffsets[t];
     const int n_t = (int)(P.toffsets[t + 1] - l0);
     const int count_t = 2 * min(n_t, P.maxT) * P.window;
-    // ---- LDS carve-up (floats): keys | scene sorted len | scene sorted idx | scene lines |
-    //      template lines | template sorted | template lengths | per-wave aligned lines | per-wave scores
-    float* s_keys = lds;
-    float* s_slen = s_keys + P.m;
-    int* s_sidx = (int*)(s_slen + P.n_s);
-    float* s_sl = (float*)(s_sidx + P.n_s);
-    float* s_tl = s_sl + 4 * P.n_s;
-    int* s_ts = (int*)(s_tl + 4 * P.lds_lines);
-    float* s_tlen = (float*)(s_ts + P.lds_lines);
-    float* L = s_tlen + P.lds_lines + (size_t)wave * P.lds_lines * 5;
-    float* sc = s_tlen + P.lds_lines + (size_t)kWavesPerBlock * P.lds_lines * 5 + (size_t)wave * (2 * P.win + 1);
-    for (int i = tid; i < P.m; i += 256) s_keys[i] = P.keys[i];
-    for (int i = tid; i < P.n_s; i += 256) { s_slen[i] = P.s_sorted_len[i]; s_sidx[i] = P.s_sorted_idx[i]; }
-    for (int i = tid; i < 4 * P.n_s; i += 256) s_sl[i] = P.slines[i];
-    for (int i = tid; i < 4 * n_t; i += 256) s_tl[i] = P.tlines[l0 * 4 + i];
-    for (int i = tid; i < n_t; i += 256) { s_ts[i] = P.tsorted[l0 + i]; s_tlen[i] = P.tlengths[l0 + i]; }
-    __syncthreads();
-    if (local >= count_t) return;  // wave-uniform
+    if (local >= count_t) return;  // wave-uniform; waves never synchronise with each other
+    // ---- per-wave LDS: keys | aligned lines | scores
+    float* s_keys = lds + (size_t)wave * (P.m + 5 * P.lds_lines + 2 * P.win + 1);
+    float* L = s_keys + P.m;
+    float* sc = L + 5 * P.lds_lines;
+    for (int i = lane; i < P.m; i += 64) s_keys[i] = P.keys[i];
     const long long cand = P.cand_offsets[t] + local;
 
     // ---- which candidate: sorted template line j, window slot wi, alignment flip
     const int flip = local & 1, pair = local >> 1;
-    const int j = pair / P.window, wi = pair - j * P.window;
-    // establishSearchStrategy<DefaultSearch>, defaultsearch.cpp:38-46
-    const int tl_local = s_ts[j];
-    const float tlen = s_tlen[tl_local];
-    const int centre = binary_search_greater(s_slen, P.n_s, tlen);
-    int rb, re;
-    centered_range(centre, P.n_s, P.maxS, rb, re);
-    const int scene_idx = s_sidx[rb + wi];
+    const int2 pr = P.pairs[(size_t)t * P.pairs_stride + pair];
+    const int tl_local = pr.x, scene_idx = pr.y;
     float tl[4], sl[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) { tl[c] = s_tl[tl_local * 4 + c]; sl[c] = s_sl[scene_idx * 4 + c]; }
+    for (int c = 0; c < 4; ++c) { tl[c] = P.tlines[(l0 + tl_local) * 4 + c]; sl[c] = P.slines[(size_t)scene_idx * 4 + c]; }
+    const float* s_tl = P.tlines + l0 * 4;  // template lines straight from HBM (coalesced 16 B per lane)
     // align + transform, defaultmatch.cpp:59-67
     float T1[6], T2[6], T[6];
     align_pair(tl, sl, T1, T2);
@@ -309,17 +314,13 @@ __global__ void __launch_bounds__(256) k_search(const SearchParams P) {
     long long best_k = 0;
     unsigned long long n_eval = 0;
     if (valid) {
-        // Consecutive multipliers move every end point by one pixel along x (|savx| == 1) or along
-        // y; reading the copy whose fastest axis is that direction puts the ~20 translations of a
-        // round on one or two 128-byte lines per end point instead of one line each.
         OptState o;
         o.L = L; o.sc = sc; o.n_t = n_t; o.W = (size_t)P.W; o.H = (size_t)P.H; o.tx = P.tx; o.ty = P.ty;
         o.savx = savx; o.savy = savy; o.lane = lane;
         o.B = P.optimizer == FDCM_BATCH_OPTIMIZE ? P.batch : 1; o.WIN = P.win; o.batch_rule = P.optimizer == FDCM_BATCH_OPTIMIZE;
         // static_cast<long>(max_mul / min_mul), batchoptimize.cpp:51,74
         o.lim_p = (long long)max_mul; o.lim_n = (long long)min_mul;
-        if (f_abs(savx) == 1.0f) optimise<true>(P.vol_t, o, best, best_k, n_eval);
-        else optimise<false>(P.vol, o, best, best_k, n_eval);
+        optimise<false>(P.vol, o, best, best_k, n_eval);
     }
     if (lane == 0) {
         fdcm_match r;
@@ -332,28 +333,34 @@ __global__ void __launch_bounds__(256) k_search(const SearchParams P) {
         r.transform[3] = T[3]; r.transform[4] = T[4]; r.transform[5] = T[5] + try_;
         if (valid) P.records[cand] = r;
         P.flags[cand] = valid ? 1 : 0;
-        if (n_eval) {
-            atomicAdd(&P.counters[0], n_eval);
-            atomicAdd(&P.counters[1], n_eval * 2ull * (unsigned long long)n_t);
-        }
+        // translations the reference's rule evaluated (reduced by the compaction kernels: one
+        // contended atomic per candidate would serialise the whole grid at ~12 ns each)
+        P.evals[cand] = (int)n_eval;
     }
 }
 
 // Positional compaction of the valid records (defaultmatch.cpp:76-86) in two small kernels:
 // per-chunk counts, then each chunk sums the counts before it, scans its flags and scatters.
 static constexpr int kChunk = 1024;
-__global__ void __launch_bounds__(256) k_chunk_counts(const int* __restrict__ flags, long long n, int* __restrict__ counts) {
-    __shared__ int part[4];
+__global__ void __launch_bounds__(256) k_chunk_counts(const int* __restrict__ flags, const int* __restrict__ evals,
+                                                      long long n, int* __restrict__ counts, int* __restrict__ evsums) {
+    __shared__ int part[4], epart[4];
     const long long c0 = (long long)blockIdx.x * kChunk;
-    int s = 0;
-    for (int i = threadIdx.x; i < kChunk; i += 256) s += (c0 + i < n) ? flags[c0 + i] : 0;
-    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    int s = 0, e = 0;
+    for (int i = threadIdx.x; i < kChunk; i += 256) {
+        if (c0 + i < n) { s += flags[c0 + i]; e += evals[c0 + i]; }
+    }
+    for (int d = 32; d >= 1; d >>= 1) { s += __shfl_xor(s, d); e += __shfl_xor(e, d); }
+    if ((threadIdx.x & 63) == 0) { part[threadIdx.x >> 6] = s; epart[threadIdx.x >> 6] = e; }
     __syncthreads();
-    if (threadIdx.x == 0) counts[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+    if (threadIdx.x == 0) {
+        counts[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+        evsums[blockIdx.x] = epart[0] + epart[1] + epart[2] + epart[3];
+    }
 }
 __global__ void __launch_bounds__(1024) k_scatter(const fdcm_match* __restrict__ records, const int* __restrict__ flags,
-                                                  long long n, const int* __restrict__ counts, int nchunks,
+                                                  long long n, const int* __restrict__ counts,
+                                                  const int* __restrict__ evsums, int nchunks,
                                                   fdcm_match* __restrict__ out, unsigned long long* __restrict__ counters) {
     __shared__ long long wsum[16];
     __shared__ long long chunk_base;
@@ -382,34 +389,20 @@ __global__ void __launch_bounds__(1024) k_scatter(const fdcm_match* __restrict__
     long long wbase = 0;
     for (int w = 0; w < wave; ++w) wbase += wsum[w];
     if (f) out[chunk_base + wbase + incl - 1] = records[i];
-    if ((int)blockIdx.x == nchunks - 1 && tid == 1023) counters[2] = (unsigned long long)(chunk_base + wbase + incl);
-}
-
-// [k][x][y] -> [k][y][x] through 64x64 LDS tiles (both sides coalesced).
-__global__ void __launch_bounds__(256) k_transpose(const float* __restrict__ src, float* __restrict__ dst, int W, int H) {
-    __shared__ float tile[64][65];
-    const size_t slice = (size_t)blockIdx.z * W * H;
-    const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 64;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    for (int r = ty; r < 64; r += 4) {  // r = x inside the tile, tx = y
-        const int x = x0 + r, y = y0 + tx;
-        if (x < W && y < H) tile[r][tx] = src[slice + (size_t)x * H + y];
+    if ((int)blockIdx.x == nchunks - 1) {
+        if (tid == 1023) counters[2] = (unsigned long long)(chunk_base + wbase + incl);
+        long long ev = 0;
+        for (int i2 = tid; i2 < nchunks; i2 += 1024) ev += evsums[i2];
+        for (int d = 32; d >= 1; d >>= 1) ev += __shfl_xor(ev, d);
+        __syncthreads();
+        if (lane == 0) wsum[wave] = ev;
+        __syncthreads();
+        if (tid == 0) {
+            long long tot = 0;
+            for (int w = 0; w < 16; ++w) tot += wsum[w];
+            counters[0] = (unsigned long long)tot;
+        }
     }
-    __syncthreads();
-    for (int r = ty; r < 64; r += 4) {  // r = y inside the tile, tx = x
-        const int x = x0 + tx, y = y0 + r;
-        if (x < W && y < H) dst[slice + (size_t)y * W + x] = tile[tx][r];
-    }
-}
-
-static void ensure_transposed(fdcm_featuremap* fm) {
-    if (fm->vol_t_valid) return;
-    const size_t bytes = (size_t)fm->m * fm->W * fm->H * sizeof(float);
-    fm->vol_t.reserve(bytes);
-    const dim3 grid((unsigned)((fm->W + 63) / 64), (unsigned)((fm->H + 63) / 64), (unsigned)fm->m);
-    hipLaunchKernelGGL(k_transpose, grid, dim3(256), 0, fm->stream, fm->vol.as<float>(), fm->vol_t.as<float>(), (int)fm->W,
-                       (int)fm->H);
-    fm->vol_t_valid = true;
 }
 
 int64_t search_capacity(const fdcm_templates* t, int64_t n_scene, int64_t maxT, int64_t maxS) {
@@ -475,14 +468,13 @@ void run_search(fdcm_featuremap* fm, const fdcm_templates* t, const float* scene
     FDCM_HIP(hipMemcpyAsync(fm->s_scene.p, hs, blob, hipMemcpyHostToDevice, st));
     const int nchunks = (int)((ncand + kChunk - 1) / kChunk);
     fm->s_records.reserve((size_t)ncand * sizeof(fdcm_match));
-    fm->s_flags.reserve((size_t)ncand * sizeof(int) + (size_t)nchunks * sizeof(int));
+    fm->s_flags.reserve(2 * ((size_t)ncand + (size_t)nchunks) * sizeof(int));
     fm->s_counter.reserve(64);
     FDCM_HIP(hipMemsetAsync(fm->s_counter.p, 0, 64, st));
     // keys live at the end of the build plan blob; for adopted volumes they are uploaded there too
     SearchParams P{};
     P.vol = fm->vol.as<float>();
-    ensure_transposed(fm);
-    P.vol_t = fm->vol_t.as<float>();
+    P.vol_t = nullptr;  // the x-fastest copy is not used: address masking showed the kernel is not gather bound
     P.keys = (const float*)((const char*)fm->plan.p + fm->off_keys);
     P.W = (int)fm->W; P.H = (int)fm->H; P.m = (int)fm->m; P.tx = fm->tx; P.ty = fm->ty;
     P.tlines = t->d_lines.as<float>();
@@ -508,15 +500,19 @@ void run_search(fdcm_featuremap* fm, const fdcm_templates* t, const float* scene
     P.lds_lines = (int)std::max<int64_t>(1, t->max_lines);
     P.records = fm->s_records.as<fdcm_match>();
     P.flags = fm->s_flags.as<int>();
+    P.evals = P.flags + ncand + nchunks;
     P.counters = fm->s_counter.as<unsigned long long>();
-    const size_t lds_floats = (size_t)P.m + 6 * (size_t)n_s + 6 * (size_t)P.lds_lines +
-                              (size_t)kWavesPerBlock * P.lds_lines * 5 + (size_t)kWavesPerBlock * (2 * P.win + 1);
+    P.pairs_stride = (int)(maxT * window);
+    fm->s_pairs.reserve(std::max<size_t>(16, (size_t)t->T * P.pairs_stride * sizeof(int2)));
+    P.pairs = fm->s_pairs.as<int2>();
+    const size_t lds_floats = (size_t)kWavesPerBlock * ((size_t)P.m + 5 * (size_t)P.lds_lines + 2 * P.win + 1);
     const size_t lds = lds_floats * sizeof(float);
     if (lds > 160 * 1024) throw std::string("scene/template too large for the search kernel's LDS staging");
     if (lds > 64 * 1024)
         FDCM_HIP(hipFuncSetAttribute((const void*)k_search, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t* ev = fm->timing.ev;
     FDCM_HIP(hipEventRecord(ev[6], st));
+    hipLaunchKernelGGL(k_pairs, dim3((unsigned)(((size_t)t->T * maxT + 255) / 256)), dim3(256), 0, st, P);
     hipLaunchKernelGGL(k_search, dim3((unsigned)((size_t)t->T * P.bpt)), dim3(256), lds, st, P);
     fdcm_match* dst = out_device;
     if (!dst) {
@@ -524,9 +520,10 @@ void run_search(fdcm_featuremap* fm, const fdcm_templates* t, const float* scene
         dst = fm->s_out.as<fdcm_match>();
     }
     int* d_counts = P.flags + ncand;
-    hipLaunchKernelGGL(k_chunk_counts, dim3((unsigned)nchunks), dim3(256), 0, st, P.flags, ncand, d_counts);
-    hipLaunchKernelGGL(k_scatter, dim3((unsigned)nchunks), dim3(1024), 0, st, P.records, P.flags, ncand, d_counts, nchunks,
-                       dst, P.counters);
+    int* d_evsums = P.evals + ncand;
+    hipLaunchKernelGGL(k_chunk_counts, dim3((unsigned)nchunks), dim3(256), 0, st, P.flags, P.evals, ncand, d_counts, d_evsums);
+    hipLaunchKernelGGL(k_scatter, dim3((unsigned)nchunks), dim3(1024), 0, st, P.records, P.flags, ncand, d_counts, d_evsums,
+                       nchunks, dst, P.counters);
     FDCM_HIP(hipEventRecord(ev[7], st));
     FDCM_HIP(hipGetLastError());
     unsigned long long hc[3] = {0, 0, 0};
