@@ -302,32 +302,42 @@ __global__ void __launch_bounds__(256) k_pass2_l2(const ColDesc* __restrict__ de
     fetch(1, av, af, az);
     fetch(2, bv, bf, bz);
     int kk = 0;
-    float base_val = cf, ag = 0.f, bg = 0.f;
-    bool has_ag = false, has_bg = false;
+    // Owner history: the current owner (cv, base_val) has owned pixels since ca; the two owners
+    // before it are (pv, pbase) since pa and (p2v, p2base) since p2a.  When entry k takes over at a
+    // pixel beyond its own position (!(z_k < v_k)) the reference reads the already written g[v_k]:
+    // it is re-evaluated from the owner of pixel v_k in the history (same expression as the pixel
+    // loop), or read back from the image if that owner is older than the history.
+    float base_val = cf;
+    int ca = 0, pv = 0, pa = 0x7fffffff, p2v = 0, p2a = 0x7fffffff;
+    float pbase = 0.f, p2base = 0.f;
     for (int q = 0; q < W; ++q) {
-        bool fresh = false;
         while (az < (float)q) {
             ++kk;
-            cv = av; cf = af;
-            base_val = ag; fresh = !has_ag;
-            av = bv; af = bf; az = bz; ag = bg; has_ag = has_bg;
-            fetch(kk + 2, bv, bf, bz);
-            has_bg = false;
-        }
-        if (fresh) {
-            base_val = cf;
-            if (cv < q && y < H) {
-                // rare read-back of the image; consumed inside the branch so that the compiler's
-                // vmcnt wait stays here and the stores of the loop are never waited for
-                const float t = row[(size_t)cv * H_];
-                asm volatile("v_mov_b32 %0, %1" : "=v"(base_val) : "v"(t));
+            const int nv_ = av;
+            float nbase = af;
+            if (!(az < (float)nv_)) {
+                int ov = cv; float ob = base_val; bool found = nv_ >= ca;
+                if (!found && nv_ >= pa) { ov = pv; ob = pbase; found = true; }
+                if (!found && nv_ >= p2a) { ov = p2v; ob = p2base; found = true; }
+                if (found) {
+                    const unsigned dv = (unsigned)(nv_ - ov);
+                    nbase = ob + (float)(dv * dv);
+                } else {
+                    float t = 0.f;
+                    if (y < H) t = row[(size_t)nv_ * H_];  // rare read-back, consumed inside the branch
+                    asm volatile("v_mov_b32 %0, %1" : "=v"(nbase) : "v"(t));
+                }
             }
+            if (ca < q) {  // the outgoing owner really owned pixels: keep it in the history
+                p2v = pv; p2base = pbase; p2a = pa;
+                pv = cv; pbase = base_val; pa = ca;
+            }
+            cv = nv_; base_val = nbase; ca = q;
+            av = bv; af = bf; az = bz;
+            fetch(kk + 2, bv, bf, bz);
         }
         const unsigned dq = (unsigned)(q - cv);  // squared modulo 2^32: exact for |q - cv| < 2^16
-        const float g = base_val + (float)(dq * dq);
-        if (active) row[(size_t)q * H_] = g;
-        if (q == av) { ag = g; has_ag = true; }
-        if (q == bv) { bg = g; has_bg = true; }
+        if (active) row[(size_t)q * H_] = base_val + (float)(dq * dq);
     }
 }
 
