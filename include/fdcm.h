@@ -129,6 +129,13 @@ int fdcm_search_device(const fdcm_featuremap* fm, const fdcm_templates* template
 int fdcm_search_last_timing(const fdcm_featuremap* fm, fdcm_search_timing* t);
 void fdcm_matches_free(fdcm_match* m);
 
+/* ---- ConcentricRangeStrategy (searchstrategies/concentricrange.h:73-84, concentricrange.cpp:29-60): the
+ *      scene lines whose centre lies in the annulus low - FLT_EPSILON < r < high around `center`.  The
+ *      strategy is DefaultSearch over those lines, so a caller searches with the filtered line array
+ *      (search<DefaultMatch> only uses the geometry of the scene lines, defaultmatch.cpp:57-61). ---- */
+int fdcm_filter_in_range(const float* lines, int64_t n_lines, const float center[2], float low_boundary,
+                         float high_boundary, int64_t* out_indices, int64_t* n_out);
+
 /* ---- tail: penalize (penaltystrategy.h) + sort_matches (matching.cpp:302-307), host side ---- */
 int fdcm_penalize(int penalty, float tau, fdcm_match* matches, int64_t n, const float* template_lengths,
                   int64_t n_templates);

@@ -193,7 +193,8 @@ class DefaultSearch:
 
 
 class ConcentricRangeStrategy:
-    """Declared for API completeness; not on the accelerated path."""
+    """DefaultSearch restricted to the scene lines whose centre lies in an annulus
+    (searchstrategies/concentricrange.h:36-84, concentricrange.cpp:29-60)."""
 
     def __init__(self, max_tmpl_lines, max_scene_lines, center_position, low_boundary, high_boundary):
         self._t, self._s = int(max_tmpl_lines), int(max_scene_lines)
@@ -260,8 +261,23 @@ def search(matcher, searcher, optimizer, featuremap, templates, scene):
     optimizer = _unwrap(optimizer, OptimizeStrategy)
     if not isinstance(matcher, DefaultMatch):
         raise TypeError("matcher must be a DefaultMatch")
-    if not isinstance(searcher, DefaultSearch):
-        raise NotImplementedError("only DefaultSearch runs on the GPU path")
+    scene_for_search = scene
+    if isinstance(searcher, ConcentricRangeStrategy):
+        # The strategy is DefaultSearch over the filtered scene lines, and search<DefaultMatch> only
+        # uses the geometry of the scene line of each combination (defaultmatch.cpp:57-61).
+        import ctypes as C
+        rec = _capi.as_records(scene)
+        if rec.shape[0]:
+            idx = _np.zeros(rec.shape[0], dtype=_np.int64)
+            n = C.c_int64()
+            ctr = _np.ascontiguousarray(searcher.get_center_position(), dtype=_np.float32)
+            _capi.check(_capi.lib().fdcm_filter_in_range(_capi.fptr(rec), rec.shape[0], _capi.fptr(ctr),
+                                                         searcher.get_low_radius_boundary(),
+                                                         searcher.get_high_radius_boundary(),
+                                                         idx.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(n)))
+            scene_for_search = _np.ascontiguousarray(rec[idx[:n.value]].T)
+    elif not isinstance(searcher, DefaultSearch):
+        raise NotImplementedError("only DefaultSearch and ConcentricRangeStrategy run on the GPU path")
     if isinstance(optimizer, BatchOptimize):
         kind, batch = _capi.BATCH_OPTIMIZE, optimizer.get_batch_size()
     elif isinstance(optimizer, DefaultOptimize):
@@ -272,7 +288,8 @@ def search(matcher, searcher, optimizer, featuremap, templates, scene):
     if not isinstance(dt3, Dt3Cpu):
         raise TypeError("featuremap must be a Dt3Cpu or FeatureMap")
     tset = templates if isinstance(templates, DeviceTemplates) else DeviceTemplates(list(templates))
-    rec = search_raw(dt3._fm, tset, scene, searcher.get_max_tmpl_lines(), searcher.get_max_scene_lines(), kind, batch)
+    rec = search_raw(dt3._fm, tset, scene_for_search, searcher.get_max_tmpl_lines(), searcher.get_max_scene_lines(), kind,
+                     batch)
     return _records_to_matches(rec)
 
 

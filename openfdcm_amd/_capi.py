@@ -64,6 +64,7 @@ SYMBOLS = [
                                      _vp, _i64p]),
     ("fdcm_search_last_timing", C.c_int, [_vp, C.POINTER(SearchTiming)]),
     ("fdcm_matches_free", None, [_vp]),
+    ("fdcm_filter_in_range", C.c_int, [_fp, C.c_int64, _fp, C.c_float, C.c_float, _i64p, _i64p]),
     ("fdcm_penalize", C.c_int, [C.c_int, C.c_float, _vp, C.c_int64, _fp, C.c_int64]),
     ("fdcm_sort_matches", C.c_int, [_vp, C.c_int64]),
     ("fdcm_selftest_atanf", C.c_int64, [C.c_uint32, C.c_uint32, C.c_uint64]),

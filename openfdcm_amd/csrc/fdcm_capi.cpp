@@ -1,5 +1,6 @@
 // fdcm_capi.cpp -- extern "C" entry points of libfdcm_hip.so (include/fdcm.h).
 #include <algorithm>
+#include <cfloat>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -338,6 +339,21 @@ int fdcm_search_last_timing(const fdcm_featuremap* fm, fdcm_search_timing* t) {
 }
 
 void fdcm_matches_free(fdcm_match* m) { std::free(m); }
+
+int fdcm_filter_in_range(const float* lines, int64_t n_lines, const float center[2], float low_boundary,
+                         float high_boundary, int64_t* out_indices, int64_t* n_out) {
+    return guarded([&] {
+        require(n_lines >= 0 && (n_lines == 0 || lines) && center && n_out && (n_lines == 0 || out_indices), "bad arguments");
+        int64_t k = 0;
+        for (int64_t i = 0; i < n_lines; ++i) {  // filterInRange, concentricrange.h:73-84
+            const float* p = lines + 4 * i;
+            const float cx = (p[2] + p[0]) / 2 - center[0], cy = (p[3] + p[1]) / 2 - center[1];
+            const float rad = std::sqrt(cx * cx + cy * cy);
+            if (rad > (low_boundary - FLT_EPSILON) && rad < high_boundary) out_indices[k++] = i;
+        }
+        *n_out = k;
+    });
+}
 
 // ------------------------------------------------------------------------------------------ tail
 int fdcm_penalize(int penalty, float tau, fdcm_match* matches, int64_t n, const float* template_lengths,

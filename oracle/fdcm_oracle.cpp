@@ -670,12 +670,37 @@ static inline std::vector<Combo> defaultSearch(const Lines& tmpl, const Lines& s
     return out;
 }
 
+// filterInRange, searchstrategies/concentricrange.h:73-84.
+static inline std::vector<long> filterInRange(const Lines& l, Point2 center, float min_radius, float max_radius) {
+    std::vector<long> idx;
+    for (long i = 0; i < l.n(); ++i) {
+        const float* p = l.line(i);
+        const float cx = (p[2] + p[0]) / 2 - center.x, cy = (p[3] + p[1]) / 2 - center.y;  // getCenter - center
+        const float rad = std::sqrt(cx * cx + cy * cy);
+        if (rad > (min_radius - std::numeric_limits<float>::epsilon()) && rad < max_radius) idx.push_back(i);
+    }
+    return idx;
+}
+
+// establishSearchStrategy<ConcentricRangeStrategy>, src/searchstrategies/concentricrange.cpp:29-60.
+static inline std::vector<Combo> concentricSearch(const Lines& tmpl, const Lines& scene, size_t maxT, size_t maxS,
+                                                  Point2 center, float lo, float hi) {
+    const std::vector<long> fidx = filterInRange(scene, center, lo, hi);
+    if (fidx.empty()) return {};
+    Lines filtered;
+    for (long i : fidx) { const float* p = scene.line(i); filtered.push(p[0], p[1], p[2], p[3]); }
+    std::vector<Combo> c = defaultSearch(tmpl, filtered, maxT, maxS);
+    for (Combo& k : c) k.sceneLine = fidx.at((size_t)k.sceneLine);  // sliceVector(filtered idx, sorted idx)
+    return c;
+}
+
 struct Match { int tmplIdx; float score; float transform[6]; };
 
 // search<DefaultMatch>, defaultmatch.cpp:32-89.
+struct Concentric { bool on = false; Point2 center{0, 0}; float lo = 0, hi = 0; };
 static inline std::vector<Match> searchDefaultMatch(const Dt3& fm, const std::vector<Lines>& templates, const Lines& scene,
                                                     size_t maxT, size_t maxS, int kind, long batch, int nthreads,
-                                                    long* n_reads_total, long* n_candidates) {
+                                                    long* n_reads_total, long* n_candidates, Concentric cr = Concentric{}) {
     std::vector<Match> all;
     if (templates.empty() || scene.n() == 0 || (fm.W == 0 && fm.H == 0)) return all;
     std::vector<Lines> aligned;
@@ -685,7 +710,8 @@ static inline std::vector<Match> searchDefaultMatch(const Dt3& fm, const std::ve
     for (size_t t = 0; t < templates.size(); ++t) {
         const Lines& tmpl = templates[t];
         if (tmpl.n() == 0) continue;
-        for (const Combo& c : defaultSearch(tmpl, scene, maxT, maxS)) {
+        for (const Combo& c : (cr.on ? concentricSearch(tmpl, scene, maxT, maxS, cr.center, cr.lo, cr.hi)
+                                     : defaultSearch(tmpl, scene, maxT, maxS))) {
             const float* scene_line = scene.line(c.sceneLine);
             const float* tmpl_line = tmpl.line(c.tmplLine);
             Point2 align_vec = normalize(scene_line);
@@ -782,6 +808,34 @@ long fdcmo_search(void* h, const float* tl, const long* offsets, long T, const f
     return (long)m.size();
 }
 void fdcmo_free_matches(FdcmoMatch* p) { std::free(p); }
+
+long fdcmo_search_concentric(void* h, const float* tl, const long* offsets, long T, const float* scene, long ns, long maxT,
+                             long maxS, float cx, float cy, float lo, float hi, int kind, long batch, int nthreads,
+                             FdcmoMatch** out) {
+    Dt3* d = (Dt3*)h;
+    std::vector<Lines> templates((size_t)T);
+    for (long t = 0; t < T; ++t) templates[t] = fromRaw(tl + 4 * offsets[t], offsets[t + 1] - offsets[t]);
+    Concentric cr; cr.on = true; cr.center = {cx, cy}; cr.lo = lo; cr.hi = hi;
+    std::vector<Match> m = searchDefaultMatch(*d, templates, fromRaw(scene, ns), (size_t)maxT, (size_t)maxS, kind, batch,
+                                              nthreads, nullptr, nullptr, cr);
+    *out = (FdcmoMatch*)std::malloc(std::max<size_t>(1, m.size()) * sizeof(FdcmoMatch));
+    for (size_t i = 0; i < m.size(); ++i) {
+        (*out)[i].tmpl_idx = m[i].tmplIdx; (*out)[i].score = m[i].score;
+        std::memcpy((*out)[i].transform, m[i].transform, 24);
+    }
+    return (long)m.size();
+}
+long fdcmo_filter_in_range(const float* lines, long n, float cx, float cy, float lo, float hi, long* out) {
+    auto v = filterInRange(fromRaw(lines, n), {cx, cy}, lo, hi);
+    for (size_t i = 0; i < v.size(); ++i) out[i] = v[i];
+    return (long)v.size();
+}
+long fdcmo_concentric_search(const float* tmpl, long nt, const float* scene, long ns, long maxT, long maxS, float cx,
+                             float cy, float lo, float hi, long* out) {
+    auto c = concentricSearch(fromRaw(tmpl, nt), fromRaw(scene, ns), (size_t)maxT, (size_t)maxS, {cx, cy}, lo, hi);
+    for (size_t i = 0; i < c.size(); ++i) { out[2 * i] = c[i].tmplLine; out[2 * i + 1] = c[i].sceneLine; }
+    return (long)c.size();
+}
 
 // ---- unit-level entry points for the known-answer tests ----
 void fdcmo_rasterize_vector(float x, float y, float* out) { Point2 r = rasterizeVector({x, y}); out[0] = r.x; out[1] = r.y; }

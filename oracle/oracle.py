@@ -50,6 +50,15 @@ def lib():
         _lib.fdcmo_search.argtypes = [vp, fp, lp, C.c_long, fp, C.c_long, C.c_long, C.c_long, C.c_int, C.c_long,
                                       C.c_int, C.POINTER(C.POINTER(_Match)), lp]
         _lib.fdcmo_free_matches.argtypes = [C.POINTER(_Match)]
+        _lib.fdcmo_search_concentric.restype = C.c_long
+        _lib.fdcmo_search_concentric.argtypes = [vp, fp, lp, C.c_long, fp, C.c_long, C.c_long, C.c_long, C.c_float, C.c_float,
+                                                 C.c_float, C.c_float, C.c_int, C.c_long, C.c_int,
+                                                 C.POINTER(C.POINTER(_Match))]
+        _lib.fdcmo_filter_in_range.restype = C.c_long
+        _lib.fdcmo_filter_in_range.argtypes = [fp, C.c_long, C.c_float, C.c_float, C.c_float, C.c_float, lp]
+        _lib.fdcmo_concentric_search.restype = C.c_long
+        _lib.fdcmo_concentric_search.argtypes = [fp, C.c_long, fp, C.c_long, C.c_long, C.c_long, C.c_float, C.c_float,
+                                                 C.c_float, C.c_float, lp]
         _lib.fdcmo_rasterize_vector.argtypes = [C.c_float, C.c_float, fp]
         _lib.fdcmo_rasterize_line.restype = C.c_long
         _lib.fdcmo_rasterize_line.argtypes = [fp, lp, lp, C.c_long]
@@ -169,6 +178,36 @@ def search(fm, templates, scene, max_tmpl_lines, max_scene_lines, kind=BATCH_OPT
         C.memmove(res.ctypes.data, out, n * MATCH_DTYPE.itemsize)
     lib().fdcmo_free_matches(out)
     return (res, stats) if return_stats else res
+
+
+def search_concentric(fm, templates, scene, max_tmpl_lines, max_scene_lines, center, low, high, kind=BATCH_OPTIMIZE,
+                      batch=10, nthreads=1):
+    flat, offsets = pack_templates(templates)
+    s = as_lines(scene)
+    out = C.POINTER(_Match)()
+    n = lib().fdcmo_search_concentric(fm._h, _fp(flat), _lp(offsets), len(templates), _fp(s), s.shape[0], max_tmpl_lines,
+                                      max_scene_lines, center[0], center[1], low, high, kind, batch, nthreads,
+                                      C.byref(out))
+    res = np.zeros(n, dtype=MATCH_DTYPE)
+    if n:
+        C.memmove(res.ctypes.data, out, n * MATCH_DTYPE.itemsize)
+    lib().fdcmo_free_matches(out)
+    return res
+
+
+def filter_in_range(lines, center, low, high):
+    s = as_lines(lines)
+    out = np.zeros(max(1, s.shape[0]), dtype=np.int64)
+    n = lib().fdcmo_filter_in_range(_fp(s), s.shape[0], center[0], center[1], low, high, _lp(out))
+    return out[:n].copy()
+
+
+def concentric_search(tmpl, scene, max_tmpl_lines, max_scene_lines, center, low, high):
+    t, s = as_lines(tmpl), as_lines(scene)
+    out = np.zeros(2 * max(1, max_tmpl_lines * max_scene_lines), dtype=np.int64)
+    n = lib().fdcmo_concentric_search(_fp(t), t.shape[0], _fp(s), s.shape[0], max_tmpl_lines, max_scene_lines,
+                                      center[0], center[1], low, high, _lp(out))
+    return out[: 2 * n].reshape(n, 2)
 
 
 # ---- unit-level helpers used by the known-answer tests ----

@@ -226,3 +226,21 @@ def test_adopted_volume_and_dt3_map_roundtrip(amd):
     a = openfdcm.search(openfdcm.DefaultMatch(), openfdcm.DefaultSearch(3, 3), openfdcm.BatchOptimize(5), fm, tm, scene)
     b = openfdcm.search(openfdcm.DefaultMatch(), openfdcm.DefaultSearch(3, 3), openfdcm.BatchOptimize(5), fm2, tm, scene)
     assert len(a) == len(b) and all(x.score == y.score and x.tmpl_idx == y.tmpl_idx for x, y in zip(a, b))
+
+
+def test_concentric_range_strategy(amd):
+    """ConcentricRangeStrategy through the mirrored API vs the oracle's restatement (concentricrange.cpp:29-60)."""
+    openfdcm = amd
+    from openfdcm_amd import synthetic
+    S = 256
+    scene = synthetic.scene(S, 60, 31)
+    tmpls = synthetic.templates(12, 9, S, 32)
+    fm = openfdcm.build_cpu_featuremap(scene, openfdcm.Dt3CpuParameters(depth=30, dt3Coeff=5.0, padding=1.0))
+    orc = O.build(scene, depth=30, coeff=5.0, padding=1.0)
+    for center, lo, hi in [((128.0, 128.0), 20.0, 90.0), ((40.0, 200.0), 0.0, 60.0), ((0.0, 0.0), 1000.0, 2000.0)]:
+        strat = openfdcm.ConcentricRangeStrategy(3, 5, center, lo, hi)
+        got = openfdcm.search(openfdcm.DefaultMatch(), strat, openfdcm.BatchOptimize(10), fm, tmpls, scene)
+        want = O.search_concentric(orc, tmpls, scene, 3, 5, center, lo, hi, kind=O.BATCH_OPTIMIZE, batch=10)
+        assert len(got) == len(want)
+        assert [m.tmpl_idx for m in got] == list(want["tmpl_idx"])
+        assert np.array_equal(np.array([m.score for m in got], dtype=np.float32).view(np.uint32), want["score"].view(np.uint32))

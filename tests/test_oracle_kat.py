@@ -299,3 +299,20 @@ def test_end_to_end_matching(n_lines, length, maxT, maxS, dist, kind):
     fm0 = O.build(np.zeros((4, 0)), depth=30, coeff=5.0, padding=2.2, distance=dist)
     assert (fm0.W, fm0.H, fm0.depth) == (0, 0, 0)
     assert len(O.search(fm0, [tmpl], np.zeros((4, 0)), maxT, maxS, kind=kind)) == 0
+
+
+# ---------------------------------------------------------------- searchstrategy.test.cpp (ConcentricRange)
+def test_concentric_range_known_answers():
+    # searchstrategy.test.cpp:91-194
+    tm = L((0, 0, 5, 5), (2, 2, 4, 4), (0, 0, 5, 0), (0, 0, 0, 5), (0, 0, 2, 2), (3, 3, 4, 4), (4, 0, 5, 5))
+    assert list(O.filter_in_range(tm, (2.5, 2.5), 0.0, 2.0)) == [0, 1, 5]
+    tmpl = L((0, 0, 2, 0), (0, 0, 3, 0), (0, 0, 1, 0), (0, 0, 8, 0))
+    assert len(O.concentric_search(tmpl, np.zeros((4, 0)), 2, 2, (0, 0), 5, 15)) == 0
+    scene = L((0, 0, 1, 0), (0, 0, 13, 0), (0, 0, 30, 0), (0, 0, 20, 0), (0, 0, 5, 0))
+    combos = {tuple(c) for c in O.concentric_search(tmpl, scene, 2, 2, (0, 0), 5, 15)}
+    assert combos and combos <= {(3, 1), (3, 3), (1, 1), (1, 3)}
+    scene = L((0, 0, 2, 0), (2, 0, 4, 0), (4, 0, 7, 0), (7, 0, 15, 0))
+    one = L((0, 0, 2, 0))
+    inf = float("inf")
+    for lo, hi, want in [(0, 2, (0, 1)), (3, 15, (0, 3)), (3, inf, (0, 3)), (2, 4, (0, 0))]:
+        assert tuple(O.concentric_search(one, scene, 1, 1, (4, 0), lo, hi)[0]) == want
