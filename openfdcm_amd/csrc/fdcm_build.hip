@@ -151,14 +151,13 @@ __device__ __forceinline__ void desc_lane(const ColDesc& d, int j, unsigned long
 // R = rows per wave (64, 32 or 16).  The chain per row is sequential, so a small volume has too
 // few rows to occupy 1024 SIMDs with full waves; with R < 64 lanes l and l + R run the same row
 // (same values, same addresses, identical control flow), which multiplies the number of waves
-// and leaves a longer LDS ring (C = 1024 / R entries) per row.
-template <int R>
+// and leaves a longer LDS ring per row.  C = ring entries per row, SG = staging entries per row for
+// the fill; the launcher picks (R, C, SG) so that every wave of the grid is resident at once.
+template <int R, int C, int SG>
 __global__ void __launch_bounds__(256) k_pass2_l2(const ColDesc* __restrict__ desc, float* __restrict__ vol, int W,
                                                   int H, int HW64, long nwaves, int* __restrict__ sv,
                                                   float* __restrict__ sf, float* __restrict__ sz) {
-    constexpr int C = 1024 / R;  // LDS ring entries per row
     constexpr int NR = 4 * R;    // distinct rows per block
-    constexpr int SG = 16;       // staging entries per row for the fill
     __shared__ int r_v[C][NR];
     __shared__ float r_f[C][NR];
     __shared__ float r_z[C][NR];
@@ -795,12 +794,14 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after) {
             int* sv = fm->stack.as<int>();
             float* sf = (float*)(sv + (size_t)W * NT);
             float* sz = sf + (size_t)W * NT;
-            if (R == 64)
-                hipLaunchKernelGGL((k_pass2_l2<64>), dim3(wblocks), dim3(256), 0, st, d_desc, vol, W, H, HW64, nwaves, sv, sf, sz);
-            else if (R == 32)
-                hipLaunchKernelGGL((k_pass2_l2<32>), dim3(wblocks), dim3(256), 0, st, d_desc, vol, W, H, HW64, nwaves, sv, sf, sz);
-            else
-                hipLaunchKernelGGL((k_pass2_l2<16>), dim3(wblocks), dim3(256), 0, st, d_desc, vol, W, H, HW64, nwaves, sv, sf, sz);
+            // LDS per block = (3 C + 3 SG) * 4R * 4 B + 4 KiB; a CU holds 160 KiB.  Small grids get the long
+            // ring (fewer HBM round trips in the fill), large grids the short one (all waves resident).
+            const bool small_grid = nwaves <= 2048;
+#define FDCM_K2(RR, CC, SS) hipLaunchKernelGGL((k_pass2_l2<RR, CC, SS>), dim3(wblocks), dim3(256), 0, st, d_desc, vol, W, H, HW64, nwaves, sv, sf, sz)
+            if (R == 64) { if (small_grid) FDCM_K2(64, 16, 8); else FDCM_K2(64, 8, 4); }
+            else if (R == 32) { if (small_grid) FDCM_K2(32, 32, 16); else FDCM_K2(32, 16, 8); }
+            else { if (small_grid) FDCM_K2(16, 64, 16); else FDCM_K2(16, 32, 8); }
+#undef FDCM_K2
         }
     }
     FDCM_HIP(hipEventRecord(ev[3], st));
