@@ -3,10 +3,18 @@
 
 Workload (config 2' of BASELINE.md): 1024x1024 synthetic scene (200 lines, seed 1), depth 30, L2,
 coeff 5, padding 1.0; 1000 templates x 32 lines (seed 2) PER GPU; DefaultSearch(4,4),
-BatchOptimize(10), DefaultMatch.  A step = one DT3 feature-map build + one search over the rank's
-template shard (+ one RCCL gather of the match records to rank 0 when N > 1).  Inputs are resident
-before the timed region (templates in HBM; the 3.2 KB scene is handed over as the C ABI's host
-pointer and uploaded inside the step).  value = raw matches produced by all ranks / second.
+BatchOptimize(10), DefaultMatch.  A step = one frame: one DT3 feature-map build + one search over
+the rank's template shard (+ one RCCL gather of the match records to rank 0 when N > 1), with the
+matches delivered to the host.  Inputs are resident before the timed region (templates in HBM; the
+3.2 KB scene is handed over as the C ABI's host pointer and uploaded inside the step).
+value = raw matches produced by all ranks / second.
+
+One frame at this size is latency bound (a sequential envelope per image row, dependent gathers
+per candidate), so by default --frames 4 frames are in flight through the library's frame pipeline
+(include/fdcm.h: each slot has its own feature map, HIP stream and host worker).  The K timed steps
+are K frames submitted and collected, in order, inside the timed region (the pipeline starts and
+ends empty).  --frames 1 is the blocking rebuild -> search sequence; its per-frame time is also
+measured (untimed extra, "single_frame_ms") so that both modes are on record.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
   roofline     -- the slowest build kernel: algorithmic bytes / its HIP-event time vs 8 TB/s HBM
@@ -17,6 +25,10 @@ import json
 import os
 import sys
 import time
+
+# One HIP stream per pipeline slot (plus torch's): ask the runtime for enough hardware queues that
+# they do not share one (read at HIP initialisation, i.e. before torch is imported).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -73,6 +85,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="2p")
+    ap.add_argument("--frames", type=int, default=4, help="frames in flight (1 = blocking rebuild -> search)")
+    ap.add_argument("--single-frames", type=int, default=20,
+                    help="frames of the untimed blocking-sequence measurement (0 = skip)")
     ap.add_argument("--templates", type=int, default=None, help="templates per GPU (default: the config's)")
     ap.add_argument("--cpu-sample", type=int, default=100, help="templates in the CPU baseline sample (0 = skip)")
     args = ap.parse_args()
@@ -101,39 +116,71 @@ def main():
     # weak scaling: every rank owns `per_gpu` templates of a global list of world * per_gpu
     all_templates = synthetic.templates(per_gpu * world, cfg["n"], cfg["S"], 2)
     searcher = ShardedSearcher(all_templates, rank, world, device)
-    fm = DeviceFeatureMap.build(scene, depth=cfg["depth"], coeff=5.0, padding=1.0, distance=cfg["distance"])
+    from openfdcm_amd.dist import ShardedPipeline
+    rec = _capi.as_records(scene)
+    F = max(1, args.frames)
+    pipe = ShardedPipeline.create(searcher, rec.shape[0], cfg["depth"], 5.0, 1.0, cfg["distance"], 4, 4,
+                           _capi.BATCH_OPTIMIZE, 10, slots=F)
+    stage_ms = {k: 0.0 for k in ("seeds_ms", "pass1_ms", "pass2_ms", "propagate_ms", "integral_ms", "total_ms")}
+    acc = {"search_kernel_ms": 0.0, "search_total_ms": 0.0, "frames": 0, "n_matches": 0}
 
-    def step():
-        fm.rebuild(scene)
-        return searcher.search(fm, scene, 4, 4, _capi.BATCH_OPTIMIZE, 10)
+    def run_frames(n, record):
+        """n frames through the pipeline: at most F in flight, collected in submission order."""
+        for _ in range(n):
+            if len(pipe.pending) == F:
+                collect(record)
+            pipe.submit(rec)
+        while pipe.pending:
+            collect(record)
+
+    def collect(record):
+        res = pipe.collect()
+        if record:
+            bt, stt = pipe.pipe.last_build_timing, pipe.pipe.last_search_timing
+            for k in stage_ms:
+                stage_ms[k] += bt[k]
+            acc["search_kernel_ms"] += stt["kernel_ms"]
+            acc["search_total_ms"] += stt["total_ms"]
+            acc["frames"] += 1
+            if res is not None:
+                acc["n_matches"] = len(res)
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    stage_ms = {k: 0.0 for k in ("seeds_ms", "pass1_ms", "pass2_ms", "propagate_ms", "integral_ms", "total_ms")}
-    search_kernel_ms = search_total_ms = 0.0
-    n_matches = 0
+    run_frames(max(args.warmup, 1), False)
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step()
-        bt, stt = fm.build_timing(), fm.search_timing()
-        for k in stage_ms:
-            stage_ms[k] += bt[k]
-        search_kernel_ms += stt["kernel_ms"]
-        search_total_ms += stt["total_ms"]
-        if res is not None:
-            n_matches = len(res)
+    run_frames(args.steps, True)
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    n_matches = acc["n_matches"]
+    search_kernel_ms, search_total_ms = acc["search_kernel_ms"], acc["search_total_ms"]
+
+    # untimed extra: the blocking sequence (one frame in flight) on this rank's shard
+    single_frame_ms = None
+    if rank == 0 and args.single_frames > 0:
+        fm = DeviceFeatureMap.build(scene, depth=cfg["depth"], coeff=5.0, padding=1.0, distance=cfg["distance"])
+        from openfdcm_amd.engine import search_raw
+        for _ in range(3):
+            fm.rebuild(scene)
+            search_raw(fm, searcher.tset, scene, 4, 4, _capi.BATCH_OPTIMIZE, 10, searcher.begin)
+        single_stage = {k: 0.0 for k in STAGE_BYTES_V}
+        t1 = time.perf_counter()
+        for _ in range(args.single_frames):
+            fm.rebuild(scene)
+            search_raw(fm, searcher.tset, scene, 4, 4, _capi.BATCH_OPTIMIZE, 10, searcher.begin)
+            bt = fm.build_timing()
+            for k in single_stage:
+                single_stage[k] += bt[k] / args.single_frames
+        single_frame_ms = (time.perf_counter() - t1) / args.single_frames * 1e3
+        fm.close()
 
     if rank == 0:
         K = args.steps
@@ -151,7 +198,10 @@ def main():
                                    f"depth {cfg['depth']}, L2, {per_gpu} templates x {cfg['n']} lines per GPU, "
                                    "DefaultSearch(4,4), BatchOptimize(10)",
                        "templates_total": per_gpu * world, "matches_per_step": n_matches,
-                       "parallelism": f"template shards x{world}, DT3 replicated, 1 RCCL gather"},
+                       "frames_in_flight": F,
+                       "parallelism": f"template shards x{world}, DT3 replicated, 1 RCCL gather per frame"},
+            "single_frame_ms": single_frame_ms,
+            "single_frame_matches_per_s": n_matches / world / (single_frame_ms * 1e-3) if single_frame_ms else None,
             "dt3_build_ms": avg["total_ms"], "dt3_build_kernels_ms": kernels_ms,
             "dt3_build_GBps_7V": 7.0 * V / (kernels_ms * 1e-3) / 1e9,
             "search_ms": search_total_ms / K, "search_kernel_ms": search_kernel_ms / K,
@@ -159,11 +209,20 @@ def main():
             "stage_ms": {k: round(v, 4) for k, v in avg.items()},
             "roofline": {"bound": "hbm", "kernel": STAGE_KERNEL[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(STAGE_KERNEL[dom]),
-                         "algorithmic_bytes_per_launch": STAGE_BYTES_V[dom] * V, "avg_launch_ms": avg[dom]},
+                         "algorithmic_bytes_per_launch": STAGE_BYTES_V[dom] * V, "avg_launch_ms": avg[dom],
+                         "frames_in_flight": F},
         }
+        if single_frame_ms:
+            # the same kernel with the GPU to itself (untimed extra): launches of concurrent frames share the
+            # CUs, so the per-launch duration inside the timed region is longer than this one
+            a1 = STAGE_BYTES_V[dom] * V / (single_stage[dom] * 1e-3) / 1e9
+            out["roofline_single_frame"] = {"kernel": STAGE_KERNEL[dom], "achieved": a1, "peak": HBM_PEAK_GBS,
+                                            "unit": "GB/s", "frac": a1 / HBM_PEAK_GBS,
+                                            "avg_launch_ms": single_stage[dom]}
         if args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(cfg, scene, all_templates[:per_gpu], min(args.cpu_sample, per_gpu))
         print(json.dumps(out), flush=True)
+    pipe.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

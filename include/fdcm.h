@@ -129,6 +129,28 @@ int fdcm_search_device(const fdcm_featuremap* fm, const fdcm_templates* template
 int fdcm_search_last_timing(const fdcm_featuremap* fm, fdcm_search_timing* t);
 void fdcm_matches_free(fdcm_match* m);
 
+/* ---- frame pipeline (throughput extension; the reference has no counterpart: its callers loop over frames
+ *      and each search() blocks, python/src/matching.cpp:283-300).  One frame at the reference's sizes is
+ *      latency bound on this GPU, so n_slots frames are kept in flight: each slot owns a feature map (own
+ *      HBM volume, workspaces, HIP stream) and a host worker thread that runs fdcm_featuremap_rebuild +
+ *      fdcm_search for the frames it is handed.  Tickets count up from 0; ticket t runs on slot t % n_slots,
+ *      so at most n_slots tickets may be outstanding.  Results per frame are exactly those of the blocking
+ *      calls.  One caller thread at a time per pipeline. ---- */
+typedef struct fdcm_pipeline fdcm_pipeline;
+int fdcm_pipeline_create(int64_t depth, float dt3_coeff, float padding, int distance, const fdcm_templates* templates,
+                         int64_t max_tmpl_lines, int64_t max_scene_lines, int optimizer, int64_t batch_size,
+                         int32_t tmpl_index_base, int n_slots, fdcm_pipeline** out);
+/* Copies the scene lines and returns at once.  out_device: NULL (matches are returned by wait as a host
+ * array) or a device buffer of fdcm_search_capacity() records that must stay valid until the wait. */
+int fdcm_pipeline_submit(fdcm_pipeline* p, const float* scene_lines, int64_t n_lines, fdcm_match* out_device,
+                         int64_t* ticket);
+/* Blocks until the frame is complete.  *out (host array, release with fdcm_matches_free) is set when the
+ * frame was submitted without a device buffer; bt / st may be NULL. */
+int fdcm_pipeline_wait(fdcm_pipeline* p, int64_t ticket, fdcm_match** out, int64_t* n_out, fdcm_build_timing* bt,
+                       fdcm_search_timing* st);
+int fdcm_pipeline_slots(const fdcm_pipeline* p, int* n_slots);
+int fdcm_pipeline_free(fdcm_pipeline* p); /* waits for frames in flight */
+
 /* ---- ConcentricRangeStrategy (searchstrategies/concentricrange.h:73-84, concentricrange.cpp:29-60): the
  *      scene lines whose centre lies in the annulus low - FLT_EPSILON < r < high around `center`.  The
  *      strategy is DefaultSearch over those lines, so a caller searches with the filtered line array

@@ -64,6 +64,13 @@ SYMBOLS = [
                                      _vp, _i64p]),
     ("fdcm_search_last_timing", C.c_int, [_vp, C.POINTER(SearchTiming)]),
     ("fdcm_matches_free", None, [_vp]),
+    ("fdcm_pipeline_create", C.c_int, [C.c_int64, C.c_float, C.c_float, C.c_int, _vp, C.c_int64, C.c_int64, C.c_int,
+                                       C.c_int64, C.c_int32, C.c_int, C.POINTER(_vp)]),
+    ("fdcm_pipeline_submit", C.c_int, [_vp, _fp, C.c_int64, _vp, _i64p]),
+    ("fdcm_pipeline_wait", C.c_int, [_vp, C.c_int64, C.POINTER(_vp), _i64p, C.POINTER(BuildTiming),
+                                     C.POINTER(SearchTiming)]),
+    ("fdcm_pipeline_slots", C.c_int, [_vp, C.POINTER(C.c_int)]),
+    ("fdcm_pipeline_free", C.c_int, [_vp]),
     ("fdcm_filter_in_range", C.c_int, [_fp, C.c_int64, _fp, C.c_float, C.c_float, _i64p, _i64p]),
     ("fdcm_penalize", C.c_int, [C.c_int, C.c_float, _vp, C.c_int64, _fp, C.c_int64]),
     ("fdcm_sort_matches", C.c_int, [_vp, C.c_int64]),

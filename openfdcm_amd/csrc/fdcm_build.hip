@@ -9,8 +9,10 @@
 //   K2 k_pass2_l2   pass 1 (from descriptors) fused into the literal in-place lower-envelope
 //                   pass along x (imgproc.h:91-130)                                      write V
 //      k_l1_*       L1: forward sweep from descriptors (write V), backward sweep (read V, write V)
-//   K3 k_propagate  orientation propagation, 4m steps per pixel in LDS (+ sqrt for L2)   read V, write V
-//   K4 k_integral   directional prefix sum per slice, one sequential chain per thread    read V, write V
+//   K3 k_propagate_reg<M> / k_propagate   orientation propagation, 4m steps per pixel in
+//                   registers (generic depth: LDS) (+ sqrt for L2)                       read V, write V
+//   K4 k_integral_shallow / k_integral_steep   directional prefix sum per slice, one sequential
+//                   float chain per lane (steep slices through LDS tiles)                read V, write V
 // Compiled with -ffp-contract=off; divide and sqrt are the correctly rounded forms.
 #include <chrono>
 #include <cstdlib>
@@ -165,7 +167,7 @@ __global__ void __launch_bounds__(256) k_pass2_l2(const ColDesc* __restrict__ de
     __shared__ float g_f[SG][NR];
     __shared__ float g_z[SG][NR];
     __shared__ uint4 dsc[4][64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const long wid = (long)blockIdx.x * 4 + wave;
     if (wid >= nwaves) return;  // wave-uniform
     constexpr int SUB = 64 / R;  // waves per 64-row chunk
@@ -484,64 +486,6 @@ __global__ void __launch_bounds__(256) k_propagate_reg(float* __restrict__ vol, 
 // shifted by dy_i = round(i r) - round((i-1) r), into the current one; the shifts telescope, so
 // pixel (x_i, c + round(i r)) belongs to chain c and each chain is one sequential float32 sum.
 // One thread per chain; the order of additions is the reference's.
-// LP = active lanes (chains) per wave.  A chain is a dependent chain of float adds, so what
-// bounds the kernel is memory latency: every lane keeps NB*U loads in flight (NB register buffers
-// of U steps, each refilled right after it is consumed), and LP < 64 multiplies the waves when a
-// volume has too few chains to fill the chip.
-template <int LP>
-__global__ void __launch_bounds__(256) k_integral(float* __restrict__ vol, int W, int H,
-                                                  const IntegralDesc* __restrict__ desc) {
-    constexpr int U = 8, NB = 6;
-    const int k = blockIdx.y;
-    const IntegralDesc d = desc[k];
-    if (d.mode != 1) return;  // steep slices: k_integral_steep
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane >= LP) return;
-    float* img = vol + (size_t)k * W * H;
-    const int t = (blockIdx.x * 4 + wave) * LP + lane;
-    const int steps = d.mode == 1 ? W : H;   // sweep length
-    const int span = d.mode == 1 ? H : W;    // extent across chains
-    const int last_off = (int)roundf((float)(steps - 1) * d.r);
-    const int cmin = -max(0, last_off), cmax = span - 1 - min(0, last_off);
-    const int c = cmin + t;
-    if (c > cmax) return;
-    const int start = d.s < 0 ? steps - 1 : 0;
-    // element (step i, offset o): mode 1 -> (x = a, y = o), mode 2 -> (x = o, y = a), a = start + i*s
-    const int stride_a = d.mode == 1 ? H : 1, stride_o = d.mode == 1 ? 1 : H;
-    float acc = 0.f;
-    bool started = false;
-    // Loads of a chain never alias its earlier stores (each pixel belongs to one chain and is
-    // visited once), so values are fetched far ahead of the running sum.
-    int idx[NB][U];
-    float v[NB][U];
-    auto fetch = [&](int b, int i0) {
-#pragma unroll
-        for (int j = 0; j < U; ++j) {
-            const int i = i0 + j;
-            const int o = c + (int)roundf((float)i * d.r);
-            const bool ok = i < steps && o >= 0 && o < span;
-            idx[b][j] = ok ? (start + i * d.s) * stride_a + o * stride_o : -1;
-            v[b][j] = ok ? img[idx[b][j]] : 0.f;
-        }
-    };
-#pragma unroll
-    for (int b = 0; b < NB; ++b) fetch(b, b * U);
-    for (int i0 = 0; i0 < steps; i0 += NB * U) {
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-#pragma unroll
-            for (int j = 0; j < U; ++j) {
-                if (idx[b][j] >= 0) {
-                    acc = started ? v[b][j] + acc : v[b][j];
-                    img[idx[b][j]] = acc;
-                    started = true;
-                }
-            }
-            fetch(b, i0 + (NB + b) * U);
-        }
-    }
-}
-
 // Chain offsets round(float(i) * r) of every slice (imgproc.h:54-55,70-71), one table row per slice.
 __global__ void k_offsets(const IntegralDesc* __restrict__ desc, int* __restrict__ offtab, int steps) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
@@ -733,7 +677,6 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after) {
     hipStream_t st = fm->stream;
     fm->W = plan.W; fm->H = plan.H; fm->m = plan.m; fm->tx = plan.tx; fm->ty = plan.ty;
     fm->keys = plan.keys;
-    fm->vol_t_valid = false;
     fm->last_build = fdcm_build_timing{};
     if (plan.m == 0 || plan.W == 0) return;
     const int W = (int)plan.W, H = (int)plan.H, m = (int)plan.m;
@@ -796,7 +739,8 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after) {
             float* sz = sf + (size_t)W * NT;
             // LDS per block = (3 C + 3 SG) * 4R * 4 B + 4 KiB; a CU holds 160 KiB.  Small grids get the long
             // ring (fewer HBM round trips in the fill), large grids the short one (all waves resident).
-            const bool small_grid = nwaves <= 2048;
+            bool small_grid = nwaves <= 2048;
+            if (const char* e = getenv("FDCM_K2_LEAN")) small_grid = atoi(e) == 0;  // tuning override
 #define FDCM_K2(RR, CC, SS) hipLaunchKernelGGL((k_pass2_l2<RR, CC, SS>), dim3(wblocks), dim3(256), 0, st, d_desc, vol, W, H, HW64, nwaves, sv, sf, sz)
             if (R == 64) { if (small_grid) FDCM_K2(64, 16, 8); else FDCM_K2(64, 8, 4); }
             else if (R == 32) { if (small_grid) FDCM_K2(32, 32, 16); else FDCM_K2(32, 16, 8); }

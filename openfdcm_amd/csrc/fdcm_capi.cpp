@@ -49,9 +49,9 @@ static void upload_keys_only(fdcm_featuremap* fm) {
 static void destroy(fdcm_featuremap* fm) {
     if (!fm) return;
     (void)hipSetDevice(fm->device);
-    fm->vol.release(); fm->vol_t.release(); fm->bitmap.release(); fm->coldesc.release(); fm->offtab.release(); fm->stack.release(); fm->plan.release(); fm->stage.release();
+    fm->vol.release(); fm->bitmap.release(); fm->coldesc.release(); fm->offtab.release(); fm->stack.release(); fm->plan.release(); fm->stage.release();
     fm->s_scene.release(); fm->s_pairs.release(); fm->s_records.release(); fm->s_flags.release(); fm->s_out.release();
-    fm->s_counter.release(); fm->s_stage.release();
+    fm->s_counter.release(); fm->s_stage.release(); fm->s_out_host.release();
     if (fm->timing.created)
         for (auto& e : fm->timing.ev) (void)hipEventDestroy(e);
     if (fm->stream) (void)hipStreamDestroy(fm->stream);
@@ -326,8 +326,7 @@ int fdcm_search(const fdcm_featuremap* fm, const fdcm_templates* templates, cons
                    tmpl_index_base, nullptr, n_out);
         *out = (fdcm_match*)std::malloc(std::max<size_t>(1, (size_t)*n_out) * sizeof(fdcm_match));
         if (!*out) throw std::string("out of host memory");
-        if (*n_out > 0)
-            FDCM_HIP(hipMemcpy(*out, f->s_out.p, (size_t)*n_out * sizeof(fdcm_match), hipMemcpyDeviceToHost));
+        if (*n_out > 0) std::memcpy(*out, f->s_out_host.p, (size_t)*n_out * sizeof(fdcm_match));
     });
 }
 

@@ -100,8 +100,6 @@ struct fdcm_featuremap {
     std::vector<float> keys;
     // device state
     fdcm::DevBuf vol;      // m*W*H float, [k][x][y]
-    fdcm::DevBuf vol_t;    // [k][y][x] copy used by the search for candidates stepping along x
-    bool vol_t_valid = false;
     fdcm::DevBuf bitmap;   // m*W*ceil(H/64) uint64 seed bits along y
     fdcm::DevBuf coldesc;  // m*ceil(H/64)*W column-chunk descriptors (16 B)
     fdcm::DevBuf offtab;   // m * max(W,H) chain offsets of the line integral
@@ -118,6 +116,7 @@ struct fdcm_featuremap {
     fdcm::DevBuf s_out;     // compacted matches
     fdcm::DevBuf s_counter;
     fdcm::PinnedBuf s_stage;
+    fdcm::PinnedBuf s_out_host;  // pinned landing area of the compacted matches (host-output searches)
     fdcm::Timing timing;
     fdcm_build_timing last_build = {};
     fdcm_search_timing last_search = {};

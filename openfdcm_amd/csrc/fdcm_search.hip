@@ -1,11 +1,14 @@
 // fdcm_search.hip -- search<DefaultMatch> + DefaultSearch + DefaultOptimize/BatchOptimize on gfx950
 // (defaultmatch.cpp:32-89, defaultsearch.cpp:29-49, batchoptimize.cpp:6-123, dt3cpu.cpp:119-179).
 //
-// One wavefront per aligned candidate (template t, template line j, scene line i, alignment); the
-// waves of a workgroup share one template, whose lines, plus the scene tables and the orientation
-// keys, are staged in LDS once per workgroup.  A wave builds its candidate itself -- align(),
-// transform(), orientation bins with the glibc atanf restatement, bounding box, rasterizeVector,
-// minmaxTranslation -- keeps the aligned lines in LDS, and then replays the optimiser.
+// k_pairs resolves DefaultSearch once per (template, template line): binary search in the sorted
+// scene lengths + window -> {template line, scene line} pairs.  k_search then runs one wavefront
+// per aligned candidate (template t, pair, alignment) with no workgroup-level synchronisation:
+// each wave has a private LDS area (keys | aligned lines, 5 floats per line | score window),
+// builds its candidate itself -- align(), transform(), orientation bins with the glibc atanf
+// restatement, bounding box, rasterizeVector, minmaxTranslation -- and replays the optimiser.
+// Results go to a positional record/flag/evaluation-count slot per candidate (no atomics);
+// k_chunk_counts + k_scatter compact them in the reference's order.
 //
 // Scoring is the gather-bound part: sum_i |I[bin_i](p1_i + t) - I[bin_i](p2_i + t)| with two
 // 4-byte gathers per line from the DT3 volume.  Two lanes share one translation (the two packet
@@ -28,7 +31,6 @@ namespace fdcm {
 struct SearchParams {
     // feature map
     const float* vol;    // [k][x][y]
-    const float* vol_t;  // [k][y][x] copy for candidates that step along x
     const float* keys;
     int W, H, m;
     float tx, ty;
@@ -474,7 +476,6 @@ void run_search(fdcm_featuremap* fm, const fdcm_templates* t, const float* scene
     // keys live at the end of the build plan blob; for adopted volumes they are uploaded there too
     SearchParams P{};
     P.vol = fm->vol.as<float>();
-    P.vol_t = nullptr;  // the x-fastest copy is not used: address masking showed the kernel is not gather bound
     P.keys = (const float*)((const char*)fm->plan.p + fm->off_keys);
     P.W = (int)fm->W; P.H = (int)fm->H; P.m = (int)fm->m; P.tx = fm->tx; P.ty = fm->ty;
     P.tlines = t->d_lines.as<float>();
@@ -528,6 +529,12 @@ void run_search(fdcm_featuremap* fm, const fdcm_templates* t, const float* scene
     FDCM_HIP(hipGetLastError());
     unsigned long long hc[3] = {0, 0, 0};
     FDCM_HIP(hipMemcpyAsync(hc, fm->s_counter.p, sizeof hc, hipMemcpyDeviceToHost, st));
+    if (!out_device && ncand > 0) {
+        // host-output search: the count is not known on the host yet, so the whole candidate capacity
+        // (32 B per candidate) goes to pinned memory in the same stream: one synchronisation per search
+        fm->s_out_host.reserve((size_t)ncand * sizeof(fdcm_match));
+        FDCM_HIP(hipMemcpyAsync(fm->s_out_host.p, dst, (size_t)ncand * sizeof(fdcm_match), hipMemcpyDeviceToHost, st));
+    }
     FDCM_HIP(hipStreamSynchronize(st));
     *n_out = (int64_t)hc[2];
     fm->last_search.evaluations = (int64_t)hc[0];

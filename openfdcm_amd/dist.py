@@ -75,3 +75,53 @@ class ShardedSearcher:
         if self.world == 1:
             return local.cpu().numpy().view(MATCH_DTYPE)
         return gather_matches(local, self.device, group=group)
+
+
+class ShardedPipeline:
+    """Frame pipeline of one rank plus the in-order gather of every frame's match records to rank 0.
+
+    `pipe` is an engine.FramePipeline over the rank's template shard (anything with its
+    submit/wait/close works; the CPU tests pass a stand-in).  Worker threads never issue
+    collectives: the caller's thread gathers frame by frame, in submission order on every rank,
+    while later frames are being computed."""
+
+    def __init__(self, pipe, world_size, device, capacity_records, slots, group=None):
+        self.pipe, self.world, self.device, self.slots, self.group = pipe, world_size, device, slots, group
+        self.bufs = None
+        if world_size > 1:  # one record buffer per slot: ticket t runs on slot t % slots (include/fdcm.h)
+            self.bufs = [torch.empty(max(1, capacity_records) * RECORD_BYTES, dtype=torch.uint8, device=device)
+                         for _ in range(slots)]
+        self.pending = []
+        self.submitted = 0
+
+    @classmethod
+    def create(cls, searcher, n_scene_lines, depth, coeff, padding, distance, max_tmpl_lines, max_scene_lines,
+               optimizer, batch_size, slots, group=None):
+        from .engine import FramePipeline
+        pipe = FramePipeline(searcher.tset, depth=depth, coeff=coeff, padding=padding, distance=distance,
+                             max_tmpl_lines=max_tmpl_lines, max_scene_lines=max_scene_lines, optimizer=optimizer,
+                             batch_size=batch_size, tmpl_index_base=searcher.begin, slots=slots)
+        cap = searcher.tset.capacity(n_scene_lines, max_tmpl_lines, max_scene_lines)
+        return cls(pipe, searcher.world, searcher.device, cap, slots, group)
+
+    def submit(self, scene_records):
+        """Queue one frame (at most `slots` may be uncollected); scene_records: (N, 4) float32."""
+        buf = self.bufs[self.submitted % self.slots] if self.bufs is not None else None
+        t = self.pipe.submit(scene_records, buf.data_ptr() if buf is not None else None, prepared=True)
+        assert t == self.submitted
+        self.submitted += 1
+        self.pending.append((t, buf))
+        return t
+
+    def collect(self):
+        """Wait for the oldest frame; returns its matches on rank 0 (all ranks' shards, rank order)."""
+        t, buf = self.pending.pop(0)
+        res = self.pipe.wait(t)
+        if buf is None:
+            return res
+        return gather_matches(buf[: int(res) * RECORD_BYTES], self.device, group=self.group)
+
+    def close(self):
+        while self.pending:
+            self.collect()
+        self.pipe.close()

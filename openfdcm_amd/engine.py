@@ -6,6 +6,20 @@ import numpy as np
 from . import _capi as capi
 
 
+def _adopt_matches(ptr, n):
+    """Wrap a library-allocated fdcm_match array as a structured numpy array without copying; the
+    allocation is released (fdcm_matches_free) when the array is garbage collected."""
+    import weakref
+    if not ptr or n == 0:
+        if ptr:
+            capi.lib().fdcm_matches_free(ptr)
+        return np.zeros(0, dtype=capi.MATCH_DTYPE)
+    raw = (C.c_char * (n * capi.MATCH_DTYPE.itemsize)).from_address(ptr.value)
+    res = np.frombuffer(raw, dtype=capi.MATCH_DTYPE)
+    weakref.finalize(raw, capi.lib().fdcm_matches_free, C.c_void_p(ptr.value))
+    return res
+
+
 class DeviceFeatureMap:
     """Owns an fdcm_featuremap handle (DT3 volume resident in HBM)."""
 
@@ -138,11 +152,7 @@ def search_raw(fm, templates, scene, max_tmpl_lines, max_scene_lines, optimizer=
     capi.check(capi.lib().fdcm_search(fm._h, templates._h, capi.fptr(rec), rec.shape[0], int(max_tmpl_lines),
                                       int(max_scene_lines), int(optimizer), int(batch_size), int(tmpl_index_base),
                                       C.byref(out), C.byref(n)))
-    res = np.zeros(n.value, dtype=capi.MATCH_DTYPE)
-    if n.value:
-        C.memmove(res.ctypes.data, out, n.value * capi.MATCH_DTYPE.itemsize)
-    capi.lib().fdcm_matches_free(out)
-    return res
+    return _adopt_matches(out, n.value)
 
 
 def search_into(fm, templates, scene, max_tmpl_lines, max_scene_lines, optimizer, batch_size, tmpl_index_base,
@@ -154,3 +164,54 @@ def search_into(fm, templates, scene, max_tmpl_lines, max_scene_lines, optimizer
                                              int(max_scene_lines), int(optimizer), int(batch_size),
                                              int(tmpl_index_base), C.c_void_p(device_ptr), C.byref(n)))
     return n.value
+
+
+class FramePipeline:
+    """Owns an fdcm_pipeline: `slots` frames in flight, each running rebuild + search on its own HIP
+    stream and host worker thread (include/fdcm.h, "frame pipeline")."""
+
+    def __init__(self, templates, depth=30, coeff=5.0, padding=2.2, distance=capi.L2, max_tmpl_lines=4,
+                 max_scene_lines=4, optimizer=capi.BATCH_OPTIMIZE, batch_size=10, tmpl_index_base=0, slots=2):
+        self.templates = templates  # keeps the handle alive
+        h = C.c_void_p()
+        capi.check(capi.lib().fdcm_pipeline_create(int(depth), float(coeff), float(padding), int(distance),
+                                                   templates._h, int(max_tmpl_lines), int(max_scene_lines),
+                                                   int(optimizer), int(batch_size), int(tmpl_index_base), int(slots),
+                                                   C.byref(h)))
+        self._h = h
+        self.slots = int(slots)
+        self.last_build_timing = None
+        self.last_search_timing = None
+
+    def submit(self, scene, device_ptr=None, prepared=False):
+        """Queue one frame; returns its ticket.  `scene` is a (4, N) LineArray, or with prepared=True the
+        (N, 4) float32 records capi.as_records() returns."""
+        rec = scene if prepared else capi.as_records(scene)
+        t = C.c_int64()
+        capi.check(capi.lib().fdcm_pipeline_submit(self._h, capi.fptr(rec), rec.shape[0],
+                                                   C.c_void_p(device_ptr) if device_ptr else None, C.byref(t)))
+        return t.value
+
+    def wait(self, ticket, to_host=True):
+        """Block until frame `ticket` is complete.  Returns the raw matches (structured array) when the frame
+        was submitted without a device buffer, else the match count."""
+        out, n = C.c_void_p(), C.c_int64()
+        bt, st = capi.BuildTiming(), capi.SearchTiming()
+        capi.check(capi.lib().fdcm_pipeline_wait(self._h, int(ticket), C.byref(out), C.byref(n), C.byref(bt),
+                                                 C.byref(st)))
+        self.last_build_timing = {k: getattr(bt, k) for k, _ in bt._fields_}
+        self.last_search_timing = {k: getattr(st, k) for k, _ in st._fields_}
+        if not out:
+            return n.value
+        return _adopt_matches(out, n.value)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            capi.lib().fdcm_pipeline_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -69,3 +69,74 @@ def test_shard_ranges_cover_and_are_contiguous():
             assert all(r[i][1] == r[i + 1][0] for i in range(w - 1))
             assert max(e - b for b, e in r) - min(e - b for b, e in r) <= 1
     assert RECORD_BYTES == 32
+
+
+class _OraclePipe:
+    """Stand-in for engine.FramePipeline on CPU: frames are searched by the oracle at submit time and
+    their records written to the caller's buffer; wait() returns the count (device-buffer mode)."""
+
+    def __init__(self, fm_builder, templates, base):
+        self.build, self.templates, self.base = fm_builder, templates, base
+        self.counts = {}
+        self.next = 0
+
+    def submit(self, rec, ptr, prepared=False):
+        import ctypes
+        from oracle import oracle as O
+        assert prepared and ptr
+        scene = np.ascontiguousarray(rec.T)
+        local = O.search(self.build(scene), self.templates, scene, 3, 3, kind=O.BATCH_OPTIMIZE, batch=10).astype(MATCH_DTYPE)
+        local["tmpl_idx"] += self.base
+        if len(local):
+            ctypes.memmove(ptr, local.ctypes.data, local.nbytes)
+        self.counts[self.next] = len(local)
+        self.next += 1
+        return self.next - 1
+
+    def wait(self, t):
+        return self.counts.pop(t)
+
+    def close(self):
+        pass
+
+
+def _pipe_worker(rank, world, port, out_path):
+    from oracle import oracle as O
+    from openfdcm_amd.dist import ShardedPipeline
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        S = 128
+        scenes = [synthetic.scene(S, 20 + 3 * i, 7 + i) for i in range(5)]  # frames differ: order must be kept
+        tmpls = synthetic.templates(5, 9, S, 6)
+        build = lambda sc: O.build(sc, depth=12, coeff=5.0, padding=1.0)  # noqa: E731
+        b, e = shard_range(len(tmpls), rank, world)
+        slots = 2
+        cap = 2 * 3 * 3 * len(tmpls) * 9
+        sp = ShardedPipeline(_OraclePipe(build, tmpls[b:e], b), world, torch.device("cpu"), cap, slots)
+        got = []
+        for sc in scenes:
+            if len(sp.pending) == slots:
+                got.append(sp.collect())
+            sp.submit(np.ascontiguousarray(np.asarray(sc, dtype=np.float32).T))
+        while sp.pending:
+            got.append(sp.collect())
+        sp.close()
+        if rank == 0:
+            assert len(got) == len(scenes)
+            for sc, res in zip(scenes, got):
+                full = O.search(build(sc), tmpls, sc, 3, 3, kind=O.BATCH_OPTIMIZE, batch=10)
+                assert res is not None and res.tobytes() == full.astype(MATCH_DTYPE).tobytes()
+            np.save(out_path, np.array([len(got)]))
+        else:
+            assert all(r is None for r in got)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_pipeline_world2(tmp_path):
+    """Frames submitted through ShardedPipeline come back in order, each the full positional list."""
+    out = str(tmp_path / "n.npy")
+    mp.spawn(_pipe_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert int(np.load(out)[0]) == 5

@@ -244,3 +244,62 @@ def test_concentric_range_strategy(amd):
         assert len(got) == len(want)
         assert [m.tmpl_idx for m in got] == list(want["tmpl_idx"])
         assert np.array_equal(np.array([m.score for m in got], dtype=np.float32).view(np.uint32), want["score"].view(np.uint32))
+
+
+# ---------------------------------------------------------------- frame pipeline (include/fdcm.h)
+@pytest.mark.parametrize("slots", [1, 3])
+def test_frame_pipeline_matches_oracle_in_order(amd, slots):
+    """Different frames in flight at once: every ticket returns the oracle's list for ITS scene."""
+    from openfdcm_amd import synthetic, _capi
+    from openfdcm_amd.engine import DeviceTemplates, FramePipeline
+    S = 160
+    scenes = [synthetic.scene(S, 18 + 4 * i, 20 + i) for i in range(7)]
+    tmpls = synthetic.templates(12, 10, S, 9)
+    tset = DeviceTemplates(tmpls)
+    pipe = FramePipeline(tset, depth=15, coeff=5.0, padding=1.0, distance=O.L2, max_tmpl_lines=3, max_scene_lines=3,
+                         optimizer=_capi.BATCH_OPTIMIZE, batch_size=10, tmpl_index_base=0, slots=slots)
+    got, tickets = [], []
+    for sc in scenes:
+        if len(tickets) == slots:
+            got.append(pipe.wait(tickets.pop(0)))
+        tickets.append(pipe.submit(sc))
+    while tickets:
+        got.append(pipe.wait(tickets.pop(0)))
+    for i, (sc, res) in enumerate(zip(scenes, got)):
+        fm = O.build(sc, depth=15, coeff=5.0, padding=1.0, distance=O.L2)
+        want = O.search(fm, tmpls, sc, 3, 3, kind=O.BATCH_OPTIMIZE, batch=10)
+        assert assert_matches_close(res, want, f"pipeline frame {i}"), f"frame {i}: not bit-identical"
+    assert pipe.last_build_timing["pass2_ms"] > 0 and pipe.last_search_timing["candidates"] > 0
+    pipe.close()
+
+
+def test_frame_pipeline_device_buffers_and_errors(amd):
+    import ctypes as C
+    import torch
+    from openfdcm_amd import synthetic, _capi
+    from openfdcm_amd.engine import DeviceTemplates, FramePipeline, DeviceFeatureMap, search_raw
+    S = 128
+    scene = synthetic.scene(S, 25, 31)
+    tmpls = synthetic.templates(9, 8, S, 32)
+    tset = DeviceTemplates(tmpls)
+    pipe = FramePipeline(tset, depth=10, coeff=5.0, padding=1.0, distance=O.L2_SQUARED, max_tmpl_lines=4,
+                         max_scene_lines=4, optimizer=_capi.DEFAULT_OPTIMIZE, batch_size=1, tmpl_index_base=100, slots=2)
+    cap = tset.capacity(25, 4, 4)
+    bufs = [torch.empty(cap * 32, dtype=torch.uint8, device="cuda") for _ in range(2)]
+    t0 = pipe.submit(scene, bufs[0].data_ptr())
+    t1 = pipe.submit(scene, bufs[1].data_ptr())
+    with pytest.raises(_capi.FdcmError):  # both slots hold uncollected frames
+        pipe.submit(scene)
+    n0, n1 = pipe.wait(t0), pipe.wait(t1)
+    with pytest.raises(_capi.FdcmError):  # a ticket is collected once
+        pipe.wait(t0)
+    fm = DeviceFeatureMap.build(scene, depth=10, coeff=5.0, padding=1.0, distance=O.L2_SQUARED)
+    want = search_raw(fm, tset, scene, 4, 4, _capi.DEFAULT_OPTIMIZE, 1, 100)
+    assert n0 == n1 == len(want) and want["tmpl_idx"].min() >= 100
+    for b in bufs:
+        got = b[: n0 * 32].cpu().numpy().view(_capi.MATCH_DTYPE)
+        assert got.tobytes() == want.tobytes()
+    # an empty scene is a valid frame (no matches), as in the blocking calls
+    t2 = pipe.submit(np.zeros((4, 0), dtype=np.float32))
+    assert len(pipe.wait(t2)) == 0
+    pipe.close()
