@@ -17,7 +17,7 @@ import sys
 
 
 def per_kernel(d, counter):
-    f = glob.glob(f"{d}/*/*counter_collection.csv")[0]
+    f = glob.glob(f"{d}/**/*counter_collection.csv", recursive=True)[0]
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == counter:
