@@ -214,6 +214,7 @@ def main():
             "dt3_build_GBps_7V": 7.0 * V / (kernels_ms * 1e-3) / 1e9,
             "search_ms": search_total_ms / K, "search_kernel_ms": search_kernel_ms / K,
             "search_matches_per_s": n_matches / (search_total_ms / K * 1e-3) if search_total_ms else None,
+            "templates_per_s": per_gpu * world * K / elapsed,
             "stage_ms": {k: round(v, 4) for k, v in avg.items()},
             "roofline": {"bound": "hbm", "kernel": STAGE_KERNEL[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(STAGE_KERNEL[dom]),

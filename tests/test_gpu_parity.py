@@ -303,3 +303,43 @@ def test_frame_pipeline_device_buffers_and_errors(amd):
     t2 = pipe.submit(np.zeros((4, 0), dtype=np.float32))
     assert len(pipe.wait(t2)) == 0
     pipe.close()
+
+
+# ---------------------------------------------------------------- BASELINE configs 3 and 5
+def test_config3_build_and_search(amd):
+    """Config 3: 2048^2, depth 60, L2_SQUARED -- the whole 1 GB volume bit for bit (compared slice by slice)
+    and the match list of the first 200 templates."""
+    import os
+    from openfdcm_amd import synthetic
+    from openfdcm_amd.engine import DeviceFeatureMap, DeviceTemplates, search_raw
+    c, scene, tmpls = synthetic.make_config("3", T=200)
+    nt = min(32, os.cpu_count() or 1)
+    dev = DeviceFeatureMap.build(scene, depth=c["depth"], coeff=5.0, padding=1.0, distance=c["distance"])
+    orc = O.build(scene, depth=c["depth"], coeff=5.0, padding=1.0, distance=c["distance"], nthreads=nt)
+    assert (dev.width, dev.height, dev.depth) == (2048, 2048, 60) == (orc.W, orc.H, orc.depth)
+    for k in range(dev.depth):
+        a, b = dev.slice(k), orc.slice(k)
+        bad = int(np.sum(a.view(np.uint32) != b.view(np.uint32)))
+        assert bad == 0, f"config 3 slice {k}: {bad} pixels differ"
+    got = search_raw(dev, DeviceTemplates(tmpls), scene, 4, 4, O.BATCH_OPTIMIZE, 10)
+    want = O.search(orc, tmpls, scene, 4, 4, kind=O.BATCH_OPTIMIZE, batch=10, nthreads=nt)
+    assert len(want) > 2000
+    assert assert_matches_close(got, want, "config 3"), "not bit-identical"
+
+
+@pytest.mark.slow
+def test_config5_sampled_slices(amd):
+    """Config 5 (stress): 4096^2, depth 180, L1 -- a 12 GB volume; seven slices compared bit for bit.
+    Needs ~30 GB of host memory for the oracle's volume; set FDCM_TEST_STRESS=1 to run."""
+    import os
+    if os.environ.get("FDCM_TEST_STRESS") != "1":
+        pytest.skip("stress case: set FDCM_TEST_STRESS=1")
+    from openfdcm_amd import synthetic
+    from openfdcm_amd.engine import DeviceFeatureMap
+    c = synthetic.CONFIGS["5"]
+    scene = synthetic.scene(c["S"], c["scene_lines"], 1)
+    dev = DeviceFeatureMap.build(scene, depth=c["depth"], coeff=5.0, padding=1.0, distance=c["distance"])
+    orc = O.build(scene, depth=c["depth"], coeff=5.0, padding=1.0, distance=c["distance"], nthreads=os.cpu_count())
+    for k in sorted(set(np.linspace(0, dev.depth - 1, 7).astype(int))):
+        a, b = dev.slice(int(k)), orc.slice(int(k))
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"config 5 slice {k}"
