@@ -86,6 +86,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="2p")
     ap.add_argument("--frames", type=int, default=4, help="frames in flight (1 = blocking rebuild -> search)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the N>1 code path (process group, device record buffers, gather) even with one rank")
     ap.add_argument("--single-frames", type=int, default=20,
                     help="frames of the untimed blocking-sequence measurement (0 = skip)")
     ap.add_argument("--templates", type=int, default=None, help="templates per GPU (default: the config's)")
@@ -107,7 +109,10 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     _capi.check(_capi.lib().fdcm_set_device(local_rank))
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
+        if "MASTER_ADDR" not in os.environ:  # --force-dist without a launcher
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=device)
 
     cfg = dict(synthetic.CONFIGS[args.config])
@@ -120,7 +125,7 @@ def main():
     rec = _capi.as_records(scene)
     F = max(1, args.frames)
     pipe = ShardedPipeline.create(searcher, rec.shape[0], cfg["depth"], 5.0, 1.0, cfg["distance"], 4, 4,
-                           _capi.BATCH_OPTIMIZE, 10, slots=F)
+                           _capi.BATCH_OPTIMIZE, 10, slots=F, gather=use_dist)
     stage_ms = {k: 0.0 for k in ("seeds_ms", "pass1_ms", "pass2_ms", "propagate_ms", "integral_ms", "total_ms")}
     acc = {"search_kernel_ms": 0.0, "search_total_ms": 0.0, "frames": 0, "n_matches": 0}
 
@@ -149,7 +154,7 @@ def main():
                 acc["n_matches"] = len(res)
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -164,7 +169,7 @@ def main():
     if os.environ.get("BENCH_DEBUG"):
         d = np.diff(np.array([t0] + stamps[-args.steps:])) * 1e3
         print("collect intervals ms:", np.round(d, 2).tolist(), file=sys.stderr)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -230,11 +235,16 @@ def main():
                                             "avg_launch_ms": single_stage[dom]}
         if args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(cfg, scene, all_templates[:per_gpu], min(args.cpu_sample, per_gpu))
-        print(json.dumps(out), flush=True)
     pipe.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL prints its version banner through C stdio, which is flushed at exit when stdout is a pipe:
+        # flush it now so that the JSON line is the last line of the output.
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

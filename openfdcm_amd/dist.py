@@ -85,10 +85,11 @@ class ShardedPipeline:
     collectives: the caller's thread gathers frame by frame, in submission order on every rank,
     while later frames are being computed."""
 
-    def __init__(self, pipe, world_size, device, capacity_records, slots, group=None):
+    def __init__(self, pipe, world_size, device, capacity_records, slots, group=None, gather=None):
         self.pipe, self.world, self.device, self.slots, self.group = pipe, world_size, device, slots, group
         self.bufs = None
-        if world_size > 1:  # one record buffer per slot: ticket t runs on slot t % slots (include/fdcm.h)
+        if world_size > 1 if gather is None else gather:
+            # one record buffer per slot: ticket t runs on slot t % slots (include/fdcm.h)
             self.bufs = [torch.empty(max(1, capacity_records) * RECORD_BYTES, dtype=torch.uint8, device=device)
                          for _ in range(slots)]
         self.pending = []
@@ -96,13 +97,13 @@ class ShardedPipeline:
 
     @classmethod
     def create(cls, searcher, n_scene_lines, depth, coeff, padding, distance, max_tmpl_lines, max_scene_lines,
-               optimizer, batch_size, slots, group=None):
+               optimizer, batch_size, slots, group=None, gather=None):
         from .engine import FramePipeline
         pipe = FramePipeline(searcher.tset, depth=depth, coeff=coeff, padding=padding, distance=distance,
                              max_tmpl_lines=max_tmpl_lines, max_scene_lines=max_scene_lines, optimizer=optimizer,
                              batch_size=batch_size, tmpl_index_base=searcher.begin, slots=slots)
         cap = searcher.tset.capacity(n_scene_lines, max_tmpl_lines, max_scene_lines)
-        return cls(pipe, searcher.world, searcher.device, cap, slots, group)
+        return cls(pipe, searcher.world, searcher.device, cap, slots, group, gather)
 
     def submit(self, scene_records):
         """Queue one frame (at most `slots` may be uncollected); scene_records: (N, 4) float32."""
