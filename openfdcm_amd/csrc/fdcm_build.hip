@@ -117,15 +117,19 @@ __global__ void __launch_bounds__(256) k_coldesc(const unsigned long long* __res
 // gives the reference's bits.  y = 64c + lane.
 template <bool SQUARED>
 __device__ __forceinline__ float column_value(unsigned long long wc, int pc, int nc, int lane, int y) {
-    int d = INT_MAX;
+    // branch-free: a missing neighbour chunk seed becomes a position 2^30 away, so "no seed in the
+    // column" is d >= 2^29 (rows are < 2^24)
+    constexpr int FAR = 1 << 30;
+    const int pe = pc == INT_MIN ? -FAR : pc, ne = nc == INT_MAX ? FAR : nc;  // uniform per column
     const unsigned long long below = wc & (~0ull >> (63 - lane));  // bits 0..lane
-    if (below) d = lane - (63 - __clzll(below));
-    else if (pc != INT_MIN) d = y - pc;
-    const unsigned long long above = wc >> lane;  // bits lane..63 shifted down
-    if (above) d = min(d, __ffsll((long long)above) - 1);
-    else if (nc != INT_MAX) d = min(d, nc - y);
-    if (d == INT_MAX) return FLT_MAX;
-    return SQUARED ? (float)((unsigned)d * (unsigned)d) : (float)d;
+    const unsigned long long above = wc & (~0ull << lane);          // bits lane..63
+    const int d_in_up = lane - (63 - __clzll(below | 1ull));         // | 1: defined for below == 0 (unused then)
+    const int d_in_dn = __ffsll((long long)(above | (1ull << 63))) - 1 - lane;
+    const int d_up = below ? d_in_up : y - pe;
+    const int d_dn = above ? d_in_dn : ne - y;
+    const int d = min(d_up, d_dn);
+    const float df = (float)d;
+    return d >= (1 << 29) ? FLT_MAX : (SQUARED ? df * df : df);  // d < 2^12: df * df is the exact integer
 }
 
 __device__ __forceinline__ void desc_lane(const ColDesc& d, int j, unsigned long long& wc, int& pc, int& nc) {
@@ -210,7 +214,8 @@ __global__ void __launch_bounds__(256) k_pass2_l2(const ColDesc* __restrict__ de
     auto process_column = [&](int q, float fq) {
         const float q2 = (float)((unsigned)q * (unsigned)q);
         while (true) {
-            const float s = (fq + q2 - tf - (float)((unsigned)tv * (unsigned)tv)) / (float)(2 * q - 2 * tv);
+            const float tvf = (float)tv;  // tvf * tvf rounds like the reference's float(long(v * v)): same integer
+            const float s = (fq + q2 - tf - tvf * tvf) / (float)(2 * q - 2 * tv);
             // (!has_u && cnt == 0): the top is entry 0 whose z is -inf; only guards non-finite input
             if (s > tz || (!has_u && cnt == 0)) {
                 if (has_u) push_down(uv, uf, uz);
