@@ -41,7 +41,7 @@ HBM_PEAK_GBS = 8000.0
 # distance transform = pass 1 writes V + pass 2 reads V and writes V (one fused kernel here, which
 # actually moves ~V + V/16); propagation reads V and writes V; line integral reads V and writes V.
 STAGE_BYTES_V = {"pass2_ms": 3.0, "propagate_ms": 2.0, "integral_ms": 2.0}
-STAGE_KERNEL = {"pass2_ms": "k_pass2_l2", "propagate_ms": "k_propagate_reg", "integral_ms": "k_integral_shallow+steep"}
+STAGE_KERNEL = {"pass2_ms": "k_pass2_l2", "propagate_ms": "k_propagate_reg", "integral_ms": "k_integral"}
 
 
 def pmc_traffic(kernel):
@@ -53,8 +53,7 @@ def pmc_traffic(kernel):
     if not files:
         return None
     ks = json.load(open(files[-1]))["kernels"]
-    tot = [v["hbm_bytes_per_launch"] for k, v in ks.items() if any(part in k for part in kernel.split("+"))
-           or kernel.split("+")[0].replace("shallow", "") in k]
+    tot = [v["hbm_bytes_per_launch"] for k, v in ks.items() if kernel in k]
     return float(sum(tot)) if tot else None
 
 

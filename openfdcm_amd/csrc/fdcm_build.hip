@@ -492,9 +492,9 @@ __global__ void __launch_bounds__(256) k_propagate_reg(float* __restrict__ vol, 
 // pixel (x_i, c + round(i r)) belongs to chain c and each chain is one sequential float32 sum.
 // One thread per chain; the order of additions is the reference's.
 // Chain offsets round(float(i) * r) of every slice (imgproc.h:54-55,70-71), one table row per slice.
-__global__ void k_offsets(const IntegralDesc* __restrict__ desc, int* __restrict__ offtab, int steps) {
+__global__ void k_offsets(const IntegralDesc* __restrict__ desc, int* __restrict__ offtab, int steps, int stride) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
-    if (i < steps) offtab[(size_t)k * steps + i] = (int)roundf((float)i * desc[k].r);
+    if (i < stride) offtab[(size_t)k * stride + i] = i < steps ? (int)roundf((float)i * desc[k].r) : 0;
 }
 
 // Shallow slices (mode 1: the sweep runs along x, the 64 chains of a wave are 64 consecutive y).
@@ -502,90 +502,76 @@ __global__ void k_offsets(const IntegralDesc* __restrict__ desc, int* __restrict
 // common case is: scalar address arithmetic, one buffer load, one add, one buffer store per step.
 // A batch of 8 steps is classified (uniformly) as outside the image, fully inside, or on the border
 // (per-lane clamping); 48 loads are kept in flight per lane.
-struct ShBuf {
-    float v[8];
-    int xo[8];  // border batches: in-row index or -1
-    int type;   // 0 outside, 1 inside, 2 border (wave-uniform)
+// Padding of the offset table per slice: the shallow kernel prefetches kShAhead steps ahead.
+static constexpr int kShU = 8, kShNB = 6, kShAhead = kShU * kShNB;
+__host__ __device__ inline int sh_off_stride(int steps) { return ((steps + kShU - 1) / kShU) * kShU + 2 * kShAhead; }
+
+// One batch of kShU consecutive steps for the 64 chains c0 + lane of a wave.  Step i touches row
+// y = c0 + lane + off[i] of column start + i*s.  Every step gets its own buffer descriptor: base =
+// the column, size = one column, so the buffer unit's range check clips the chains to the image
+// (a lane outside the column, or a step past the end, loads 0 / drops its store) and the only
+// per-lane arithmetic is one add.  No branch: every batch issues exactly kShU memory operations,
+// so the compiler can count them and never waits for more than it needs.
+struct ShAddr {
+    __amdgpu_buffer_rsrc_t rs[kShU];
+    unsigned voff[kShU];
 };
-
-__device__ __forceinline__ void sh_fetch(ShBuf& B, __amdgpu_buffer_rsrc_t rs, const int* __restrict__ off, int i0,
-                                         int steps, int span, int H, int start, int s, int c0, int lane) {
-    if (i0 >= steps) { B.type = 0; return; }
-    const int ilast = min(i0 + 7, steps - 1);
-    const int oa = off[i0], ob = off[ilast];
-    const int omin = min(oa, ob), omax = max(oa, ob);
-    if (c0 + 63 + omax < 0 || c0 + omin >= span) { B.type = 0; return; }
-    if (c0 + omin >= 0 && c0 + 63 + omax < span && i0 + 8 <= steps) {
-        B.type = 1;
+// col: running pointer to the column of step i0 (advanced by step_elems per step, also past the
+// last step: those descriptors are never dereferenced because their lane offsets are out of range).
+__device__ __forceinline__ void sh_addr(ShAddr& A, float*& col, long step_elems, const int* __restrict__ off, int i0,
+                                        int steps, int H, int c0, int lane4) {
+    // 8 dwords with scalar vector loads: the table is padded and its rows are 32-byte aligned
+    const int4* op = reinterpret_cast<const int4*>(off + i0);
+    const int4 oa = op[0], ob = op[1];
+    const int o[kShU] = {oa.x, oa.y, oa.z, oa.w, ob.x, ob.y, ob.z, ob.w};
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int soff = ((start + (i0 + j) * s) * H + c0 + off[i0 + j]) * 4;
-            B.v[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, lane * 4, soff, 0));
-        }
-        return;
-    }
-    B.type = 2;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int i = i0 + j;
-        const int x = c0 + lane + off[min(i, steps - 1)];
-        const bool ok = i < steps && x >= 0 && x < span;
-        B.xo[j] = ok ? x : -1;
-        const int soff = (start + min(i, steps - 1) * s) * H * 4;
-        const float t = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, max(0, min(x, span - 1)) * 4, soff, 0));
-        B.v[j] = ok ? t : 0.f;
+    for (int j = 0; j < kShU; ++j) {
+        const unsigned ob4 = i0 + j < steps ? (unsigned)(c0 + o[j]) * 4u : 0x80000000u;  // scalar
+        A.voff[j] = (unsigned)lane4 + ob4;  // negative rows wrap to >= 2^31: out of range
+        A.rs[j] = __builtin_amdgcn_make_buffer_rsrc(col, 0, (unsigned)H * 4u, 0x00020000);
+        col += step_elems;
     }
 }
 
-__device__ __forceinline__ void sh_consume(const ShBuf& B, float& acc, __amdgpu_buffer_rsrc_t rs,
-                                           const int* __restrict__ off, int i0, int steps, int H, int start, int s,
-                                           int c0, int lane) {
-    if (B.type == 0) return;
-    if (B.type == 1) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            acc = B.v[j] + acc;  // 0 + v == v exactly before the chain starts (v >= +0)
-            const int soff = ((start + (i0 + j) * s) * H + c0 + off[i0 + j]) * 4;
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc), rs, lane * 4, soff, 0);
-        }
-        return;
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        acc = B.v[j] + acc;
-        if (B.xo[j] >= 0) {
-            const int soff = (start + min(i0 + j, steps - 1) * s) * H * 4;
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc), rs, B.xo[j] * 4, soff, 0);
-        }
-    }
-}
-
-__global__ void __launch_bounds__(256) k_integral_shallow(float* __restrict__ vol, int W, int H,
-                                                          const IntegralDesc* __restrict__ desc,
-                                                          const int* __restrict__ offtab) {
-    constexpr int NB = 6;
-    const int k = blockIdx.y;
-    const IntegralDesc d = desc[k];
-    if (d.mode != 1) return;
-    const int lane = threadIdx.x & 63;
+__device__ __forceinline__ void integral_shallow(float* __restrict__ vol, int W, int H, const IntegralDesc& d, int k,
+                                                 const int* __restrict__ offtab) {
+    constexpr int NB = kShNB, U = kShU;
+    const int lane4 = (threadIdx.x & 63) * 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int steps = W, span = H;
-    const int* off = offtab + (size_t)k * steps;
+    const int* off = offtab + (size_t)k * sh_off_stride(steps);
     const int last_off = off[steps - 1];
     const int cmin = -max(0, last_off), cmax = span - 1 - min(0, last_off);
     const int c0 = cmin + ((int)blockIdx.x * 4 + wave) * 64;
     if (c0 > cmax) return;
     const int start = d.s < 0 ? steps - 1 : 0;
-    const auto rs = __builtin_amdgcn_make_buffer_rsrc(vol + (size_t)k * W * H, 0, (unsigned)((size_t)W * H * 4), 0x00020000);
+    const long step_elems = (long)d.s * H;
+    float* col_f = vol + (size_t)k * W * H + (size_t)start * H;  // column of the next step to fetch
+    float* col_c = col_f;                                         // column of the next step to consume
     float acc = 0.f;
-    ShBuf B[NB];
+    float v[NB][U];
 #pragma unroll
-    for (int b = 0; b < NB; ++b) sh_fetch(B[b], rs, off, b * 8, steps, span, H, start, d.s, c0, lane);
-    for (int i0 = 0; i0 < steps; i0 += NB * 8) {
+    for (int b = 0; b < NB; ++b) {
+        ShAddr A;
+        sh_addr(A, col_f, step_elems, off, b * U, steps, H, c0, lane4);
+#pragma unroll
+        for (int j = 0; j < U; ++j) v[b][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(A.rs[j], A.voff[j], 0, 0));
+    }
+    // Loads of a chain never alias its earlier stores (each pixel belongs to one chain and is visited
+    // once), so values are fetched kShAhead steps ahead of the running sum.
+    for (int i0 = 0; i0 < steps; i0 += NB * U) {
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-            sh_consume(B[b], acc, rs, off, i0 + b * 8, steps, H, start, d.s, c0, lane);
-            sh_fetch(B[b], rs, off, i0 + (NB + b) * 8, steps, span, H, start, d.s, c0, lane);
+            ShAddr A;
+            sh_addr(A, col_c, step_elems, off, i0 + b * U, steps, H, c0, lane4);
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                acc = v[b][j] + acc;  // out-of-image loads are +0: 0 + acc == acc exactly (acc >= +0)
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc), A.rs[j], A.voff[j], 0, 0);
+            }
+            sh_addr(A, col_f, step_elems, off, i0 + (NB + b) * U, steps, H, c0, lane4);
+#pragma unroll
+            for (int j = 0; j < U; ++j) v[b][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(A.rs[j], A.voff[j], 0, 0));
         }
     }
 }
@@ -597,14 +583,9 @@ __global__ void __launch_bounds__(256) k_integral_shallow(float* __restrict__ vo
 // stored back the same way.  The next tile's loads are in flight while the current one is
 // summed and stored.  Only elements that belong to the block's own chains are written.
 template <int XC>
-__global__ void __launch_bounds__(256) k_integral_steep(float* __restrict__ vol, int W, int H,
-                                                        const IntegralDesc* __restrict__ desc) {
+__device__ __forceinline__ void integral_steep(float* __restrict__ vol, int W, int H, const IntegralDesc& d, int k) {
     constexpr int TS = 32, TW = XC + TS, PASSES = TW / 8;
     __shared__ float tile[2][TW][TS + 1];
-    const int k = blockIdx.y;
-    const IntegralDesc d = desc[k];
-    if (d.mode != 2) return;
-    float* img = vol + (size_t)k * W * H;
     const int steps = H, span = W;
     const int last_off = (int)roundf((float)(steps - 1) * d.r);
     const int cmin = -max(0, last_off), cmax = span - 1 - min(0, last_off);
@@ -615,25 +596,31 @@ __global__ void __launch_bounds__(256) k_integral_steep(float* __restrict__ vol,
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int prow = tid & 31, pcol = tid >> 5;  // load/store mapping: 8 columns x 32 rows per pass
     const int ntiles = (steps + TS - 1) / TS;
+    // The slice through a buffer descriptor: a column left or right of the image gives a byte offset
+    // that is negative (wraps above 2^31) or >= W*H*4, both out of range, so only the sweep
+    // direction needs an explicit test.  Out-of-range loads return 0, stores are dropped, and no
+    // memory operation sits behind a branch: the compiler counts them exactly, which lets the
+    // loads of two tiles stay in flight behind the stores of the previous ones.
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc(vol + (size_t)k * W * H, 0, (unsigned)((size_t)W * H * 4), 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    const int colB = H * 4;
     auto off_at = [&](int i) { return (int)roundf((float)i * d.r); };  // chain offset at step i (imgproc.h:70-71)
     auto xbase = [&](int t) { return c0 + min(off_at(t * TS), off_at(min(t * TS + TS - 1, steps - 1))); };
-    float regs[PASSES];
-    auto load_tile = [&](int t) {
-        const int i = t * TS + prow, y = start + i * d.s, xb = xbase(t);
+    auto load_tile = [&](int t, float (&regs)[PASSES]) {
+        const int i = t * TS + prow, xb = xbase(t);
+        const unsigned yb = i < steps ? (unsigned)((start + i * d.s) * 4) : OOB;
+        const unsigned cb = (unsigned)((xb + pcol) * colB) + yb;
 #pragma unroll
-        for (int p = 0; p < PASSES; ++p) {
-            const int x = xb + p * 8 + pcol;
-            regs[p] = (i < steps && x >= 0 && x < W) ? img[(size_t)x * H + y] : 0.f;
-        }
+        for (int p = 0; p < PASSES; ++p)
+            regs[p] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, cb + (unsigned)(p * 8 * colB), 0, 0));
     };
     float acc = 0.f;
-    load_tile(0);
-    for (int t = 0; t < ntiles; ++t) {
+    auto process = [&](int t, float (&regs)[PASSES]) {  // regs hold tile t on entry, tile t + 2 on exit
         const int buf = t & 1, i0 = t * TS, xb = xbase(t);
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) tile[buf][p * 8 + pcol][prow] = regs[p];
         __syncthreads();
-        if (t + 1 < ntiles) load_tile(t + 1);
+        load_tile(t + 2, regs);  // past the last tile every load is out of range
         if (wave == 0) {
             const int c = c0 + lane;
             const int my_off = off_at(i0 + (lane & 31));  // lane j < 32 holds the offset of step i0 + j
@@ -655,16 +642,38 @@ __global__ void __launch_bounds__(256) k_integral_steep(float* __restrict__ vol,
             }
         }
         __syncthreads();
-        {
-            const int i = i0 + prow, y = start + i * d.s;
+        {  // only elements of the block's own chains are written back
+            const int i = i0 + prow;
             const int o = off_at(i);
+            const unsigned yb = i < steps ? (unsigned)((start + i * d.s) * 4) : OOB;
 #pragma unroll
             for (int p = 0; p < PASSES; ++p) {
                 const int x = xb + p * 8 + pcol, c = x - o;
-                if (i < steps && x >= 0 && x < W && c >= c0 && c <= c_hi) img[(size_t)x * H + y] = tile[buf][p * 8 + pcol][prow];
+                const unsigned voff = (c >= c0 && c <= c_hi) ? (unsigned)(x * colB) + yb : OOB;
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(tile[buf][p * 8 + pcol][prow]), rs, voff, 0, 0);
             }
         }
+    };
+    float ra[PASSES], rb[PASSES];
+    load_tile(0, ra);
+    load_tile(1, rb);
+    for (int t = 0; t < ntiles; t += 2) {
+        process(t, ra);
+        if (t + 1 < ntiles) process(t + 1, rb);
     }
+}
+
+// One launch for all slices: blockIdx.y = slice, and the slice's mode picks the sweep.  Shallow and
+// steep slices are independent, so their (latency-bound) blocks overlap instead of running as two
+// kernels back to back.  Grid x covers the steep case (64 chains per block); a shallow block takes
+// 256 chains and the surplus blocks of a shallow slice exit at once.
+__global__ void __launch_bounds__(256) k_integral(float* __restrict__ vol, int W, int H,
+                                                  const IntegralDesc* __restrict__ desc,
+                                                  const int* __restrict__ offtab) {
+    const int k = blockIdx.y;
+    const IntegralDesc d = desc[k];
+    if (d.mode == 1) integral_shallow(vol, W, H, d, k, offtab);
+    else if (d.mode == 2) integral_steep<64>(vol, W, H, d, k);
 }
 
 // ------------------------------------------------------------------------------------------ driver
@@ -685,7 +694,7 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after) {
     fm->last_build = fdcm_build_timing{};
     if (plan.m == 0 || plan.W == 0) return;
     const int W = (int)plan.W, H = (int)plan.H, m = (int)plan.m;
-    if (plan.W > 32768 || plan.H > 32768) throw std::string("feature size above 32768 is not supported");
+    if (plan.W > 16384 || plan.H > 16384) throw std::string("feature size above 16384 is not supported");  // 32-bit byte offsets inside a slice
     const int HW64 = (H + 63) / 64;
     const size_t npix = (size_t)W * H, nvox = npix * m;
     const long nrows = (long)m * H, ncols = (long)m * W;
@@ -779,13 +788,11 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after) {
     if (stop_after >= 3) {
         const int chains = 2 * (W > H ? W : H);
         const int steps = W > H ? W : H;
-        fm->offtab.reserve((size_t)m * steps * sizeof(int));
+        const int off_stride = sh_off_stride((int)steps);
+        fm->offtab.reserve((size_t)m * off_stride * sizeof(int));
         int* d_off = fm->offtab.as<int>();
-        hipLaunchKernelGGL(k_offsets, dim3((unsigned)((steps + 255) / 256), (unsigned)m), dim3(256), 0, st, d_int, d_off, steps);
-        hipLaunchKernelGGL(k_integral_shallow, dim3((unsigned)((chains + 255) / 256), (unsigned)m), dim3(256), 0, st, vol, W, H,
-                           d_int, d_off);
-        hipLaunchKernelGGL(k_integral_steep<64>, dim3((unsigned)((chains + 63) / 64), (unsigned)m), dim3(256), 0, st, vol, W, H,
-                           d_int);
+        hipLaunchKernelGGL(k_offsets, dim3((unsigned)((off_stride + 255) / 256), (unsigned)m), dim3(256), 0, st, d_int, d_off, (int)steps, off_stride);
+        hipLaunchKernelGGL(k_integral, dim3((unsigned)((chains + 63) / 64), (unsigned)m), dim3(256), 0, st, vol, W, H, d_int, d_off);
     }
     FDCM_HIP(hipEventRecord(ev[5], st));
     FDCM_HIP(hipGetLastError());
