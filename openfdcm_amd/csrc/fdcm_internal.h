@@ -114,6 +114,7 @@ struct fdcm_featuremap {
     fdcm::DevBuf s_records; // per-candidate result records
     fdcm::DevBuf s_flags;   // per-candidate valid flag + scan scratch
     fdcm::DevBuf s_out;     // compacted matches
+    fdcm::DevBuf s_work;    // search work list: valid pairs grouped by scene line
     fdcm::DevBuf s_counter;
     fdcm::PinnedBuf s_stage;
     fdcm::PinnedBuf s_out_host;  // pinned landing area of the compacted matches (host-output searches)

@@ -55,7 +55,11 @@ struct SearchParams {
     const long long* cand_offsets;  // T+1
     const int2* pairs;              // per template, per (j, wi): {template line, scene line}
     int pairs_stride;               // maxT * window
-    int bpt;                        // workgroups per template
+    int bpt;                        // workgroups per template (template-major order, when there is no work list)
+    const int2* work;               // valid pairs {template, pair slot} grouped by scene line (or null)
+    long long ncand;                // candidates in total
+    int nblocks;                    // k_search workgroups
+    int xcd_parts;                  // 1: every XCD takes its own contiguous part of the work list
     int lds_lines;                  // capacity (lines) of the LDS template / aligned-line areas
     // outputs
     fdcm_match* records;
@@ -244,21 +248,138 @@ __global__ void k_pairs(const SearchParams P) {
     const int t = gidx / per, j = gidx - t * per;
     const long long l0 = P.toffsets[t];
     const int n_t = (int)(P.toffsets[t + 1] - l0);
-    if (j >= n_t) return;
+    int2* out = const_cast<int2*>(P.pairs) + (size_t)t * P.pairs_stride + (size_t)j * P.window;
+    if (j >= n_t) {  // fewer lines than max_tmpl_lines: no pairs in these slots
+        for (int wi = 0; wi < P.window; ++wi) out[wi] = make_int2(-1, -1);
+        return;
+    }
     const int tl_local = P.tsorted[l0 + j];
     const float tlen = P.tlengths[l0 + tl_local];
     const int centre = binary_search_greater(P.s_sorted_len, P.n_s, tlen);
     int rb, re;
     centered_range(centre, P.n_s, P.maxS, rb, re);
-    int2* out = const_cast<int2*>(P.pairs) + (size_t)t * P.pairs_stride + (size_t)j * P.window;
     for (int wi = 0; wi < P.window; ++wi) out[wi] = make_int2(tl_local, P.s_sorted_idx[rb + wi]);
+}
+
+// Work list: the valid (template, pair slot) entries grouped by scene line.  A candidate's gathers
+// fall inside the template's bounding box laid along its scene line (plus the walk of the
+// optimiser), a few MB over all slices, and DefaultSearch sends most candidates to the few scene
+// lines whose length is close to the templates' longest lines.  In template-major order consecutive
+// waves touch unrelated regions and every L2 keeps missing; grouped by scene line, the waves in
+// flight at any time share one or two regions.  Output positions are
+// independent of the processing order (k_chunk_counts / k_scatter compact by candidate position).
+// One workgroup: counting sort by scene line (hashed into kWorkBins) with wave-aggregated LDS
+// atomics; the order inside a group is arbitrary.
+static constexpr int kWorkBins = 8192;
+// bin of a pair: its scene line.  (Splitting the two alignments of a pair into separate groups was
+// measured slower: 0.37-0.41 ms against 0.30 ms.)
+__device__ __forceinline__ int work_key(int scene_idx) { return scene_idx & (kWorkBins - 1); }
+// wave-aggregated "take a unique rank inside bins[key]": one LDS atomic per distinct key of the wave
+__device__ __forceinline__ int work_rank(int* bins, int key, bool valid, int lane) {
+    unsigned long long todo = __ballot(valid);
+    int rank = 0;
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int k = __shfl(key, leader);
+        const unsigned long long same = __ballot(valid && key == k) & todo;
+        int base = 0;
+        if (lane == leader) base = atomicAdd(&bins[k], __popcll(same));
+        base = __shfl(base, leader);
+        if (valid && key == k) rank = base + __popcll(same & ((1ull << lane) - 1ull));
+        todo &= ~same;
+    }
+    return rank;
+}
+// exclusive scan of the bins in place: kWorkBins / 1024 bins per thread + a block scan of the sums
+__device__ __forceinline__ void work_scan(int* bins, int* partial, int tid) {
+    constexpr int PER = kWorkBins / 1024;
+    int loc[PER], sum = 0;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) { loc[q] = sum; sum += bins[tid * PER + q]; }
+    partial[tid] = sum;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const int v = tid >= d ? partial[tid - d] : 0;
+        __syncthreads();
+        partial[tid] += v;
+        __syncthreads();
+    }
+    const int excl = partial[tid] - sum;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) bins[tid * PER + q] = excl + loc[q];
+}
+
+// REG: up to 16 slots per thread, kept in registers (all loads in flight at once, no second pass
+// over memory); otherwise the ranks go through slot_rank.
+template <bool REG>
+__global__ void __launch_bounds__(1024) k_worklist(const SearchParams P, long long n_slots, int2* __restrict__ work,
+                                                   int* __restrict__ slot_rank) {
+    __shared__ int bins[kWorkBins];
+    __shared__ int partial[1024];
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int i = tid; i < kWorkBins; i += 1024) bins[i] = 0;
+    if (REG) {
+        constexpr int RR = 16;
+        int2 pr[RR];
+        int rk[RR];
+#pragma unroll
+        for (int r = 0; r < RR; ++r) {
+            const long long i = (long long)r * 1024 + tid;
+            pr[r] = i < n_slots ? P.pairs[i] : make_int2(-1, -1);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < RR; ++r) rk[r] = work_rank(bins, work_key(pr[r].y), pr[r].x >= 0, lane);
+        __syncthreads();
+        work_scan(bins, partial, tid);
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < RR; ++r) {
+            if (pr[r].x < 0) continue;
+            const long long i = (long long)r * 1024 + tid;
+            const int t = (int)(i / P.pairs_stride);
+            work[bins[work_key(pr[r].y)] + rk[r]] = make_int2(t, (int)(i - (long long)t * P.pairs_stride));
+        }
+        return;
+    }
+    __syncthreads();
+    const long long rounds = (n_slots + 1023) / 1024;
+    for (long long r = 0; r < rounds; ++r) {
+        const long long i = r * 1024 + tid;
+        const int2 pr = i < n_slots ? P.pairs[i] : make_int2(-1, -1);
+        const int rank = work_rank(bins, work_key(pr.y), pr.x >= 0, lane);
+        if (pr.x >= 0) slot_rank[i] = rank;
+    }
+    __syncthreads();
+    work_scan(bins, partial, tid);
+    __syncthreads();
+    for (long long i = tid; i < n_slots; i += 1024) {  // scatter
+        const int2 pr = P.pairs[i];
+        if (pr.x < 0) continue;
+        const int t = (int)(i / P.pairs_stride);
+        work[bins[work_key(pr.y)] + slot_rank[i]] = make_int2(t, (int)(i - (long long)t * P.pairs_stride));
+    }
 }
 
 __global__ void __launch_bounds__(256) k_search(const SearchParams P) {
     extern __shared__ float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int t = blockIdx.x / P.bpt;
-    const int local = (blockIdx.x - t * P.bpt) * kWavesPerBlock + wave;
+    int t, local;
+    if (P.work) {
+        // List order = launch order: workgroups go round-robin to the XCDs, so all XCDs work on the same
+        // scene line at the same time.  (Giving every XCD its own contiguous part of the list was
+        // measured slower: 0.32-0.39 ms against 0.27-0.29 ms.)
+        const int per_xcd = (P.nblocks + 7) >> 3;
+        const long long w = P.xcd_parts ? ((long long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3)) * kWavesPerBlock + wave
+                                        : (long long)blockIdx.x * kWavesPerBlock + wave;
+        if (w >= P.ncand) return;  // wave-uniform; waves never synchronise with each other
+        const int2 e = P.work[w >> 1];  // the two alignments of a pair run next to each other
+        t = e.x;
+        local = e.y * 2 + (int)(w & 1);
+    } else {
+        t = blockIdx.x / P.bpt;
+        local = (blockIdx.x - t * P.bpt) * kWavesPerBlock + wave;
+    }
     const long long l0 = P.toffsets[t];
     const int n_t = (int)(P.toffsets[t + 1] - l0);
     const int count_t = 2 * min(n_t, P.maxT) * P.window;
@@ -498,6 +619,8 @@ void run_search(fdcm_featuremap* fm, const fdcm_templates* t, const float* scene
     P.base = base;
     P.cand_offsets = (const long long*)(ds + o_coff);
     P.bpt = (int)((cpt_max + kWavesPerBlock - 1) / kWavesPerBlock);
+    P.ncand = ncand;
+    P.xcd_parts = getenv("FDCM_SEARCH_XCD_PARTS") ? atoi(getenv("FDCM_SEARCH_XCD_PARTS")) : 0;
     P.lds_lines = (int)std::max<int64_t>(1, t->max_lines);
     P.records = fm->s_records.as<fdcm_match>();
     P.flags = fm->s_flags.as<int>();
@@ -514,7 +637,21 @@ void run_search(fdcm_featuremap* fm, const fdcm_templates* t, const float* scene
     hipEvent_t* ev = fm->timing.ev;
     FDCM_HIP(hipEventRecord(ev[6], st));
     hipLaunchKernelGGL(k_pairs, dim3((unsigned)(((size_t)t->T * maxT + 255) / 256)), dim3(256), 0, st, P);
-    hipLaunchKernelGGL(k_search, dim3((unsigned)((size_t)t->T * P.bpt)), dim3(256), lds, st, P);
+    const long long n_slots = (long long)t->T * P.pairs_stride;
+    static const bool no_worklist = getenv("FDCM_SEARCH_TEMPLATE_MAJOR") != nullptr;  // tuning override
+    if (!no_worklist && n_slots <= 0x7fffffffll) {
+        const size_t work_bytes = ((size_t)(ncand / 2) * sizeof(int2) + 15) & ~(size_t)15;
+        fm->s_work.reserve(work_bytes + (size_t)n_slots * sizeof(int));
+        int* slot_rank = (int*)((char*)fm->s_work.p + work_bytes);
+        if (n_slots <= 16 * 1024) hipLaunchKernelGGL(k_worklist<true>, dim3(1), dim3(1024), 0, st, P, n_slots, fm->s_work.as<int2>(), slot_rank);
+        else hipLaunchKernelGGL(k_worklist<false>, dim3(1), dim3(1024), 0, st, P, n_slots, fm->s_work.as<int2>(), slot_rank);
+        P.work = fm->s_work.as<int2>();
+        P.nblocks = (int)(((ncand + kWavesPerBlock - 1) / kWavesPerBlock + 7) / 8 * 8);
+    } else {
+        P.work = nullptr;
+        P.nblocks = (int)((size_t)t->T * P.bpt);
+    }
+    hipLaunchKernelGGL(k_search, dim3((unsigned)P.nblocks), dim3(256), lds, st, P);
     fdcm_match* dst = out_device;
     if (!dst) {
         fm->s_out.reserve((size_t)ncand * sizeof(fdcm_match));
