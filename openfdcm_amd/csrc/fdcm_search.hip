@@ -274,21 +274,11 @@ static constexpr int kWorkBins = 8192;
 // bin of a pair: its scene line.  (Splitting the two alignments of a pair into separate groups was
 // measured slower: 0.37-0.41 ms against 0.30 ms.)
 __device__ __forceinline__ int work_key(int scene_idx) { return scene_idx & (kWorkBins - 1); }
-// wave-aggregated "take a unique rank inside bins[key]": one LDS atomic per distinct key of the wave
+// take a unique rank inside bins[key]: one LDS atomic per lane (same-address lanes serialise inside
+// the LDS unit, ~1 per cycle, which is far cheaper than aggregating them with ballots and shuffles)
 __device__ __forceinline__ int work_rank(int* bins, int key, bool valid, int lane) {
-    unsigned long long todo = __ballot(valid);
-    int rank = 0;
-    while (todo) {
-        const int leader = __ffsll((long long)todo) - 1;
-        const int k = __shfl(key, leader);
-        const unsigned long long same = __ballot(valid && key == k) & todo;
-        int base = 0;
-        if (lane == leader) base = atomicAdd(&bins[k], __popcll(same));
-        base = __shfl(base, leader);
-        if (valid && key == k) rank = base + __popcll(same & ((1ull << lane) - 1ull));
-        todo &= ~same;
-    }
-    return rank;
+    (void)lane;
+    return valid ? atomicAdd(&bins[key], 1) : 0;
 }
 // exclusive scan of the bins in place: kWorkBins / 1024 bins per thread + a block scan of the sums
 __device__ __forceinline__ void work_scan(int* bins, int* partial, int tid) {
