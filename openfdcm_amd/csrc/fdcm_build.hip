@@ -159,7 +159,7 @@ __device__ __forceinline__ void desc_lane(const ColDesc& d, int j, unsigned long
 // (same values, same addresses, identical control flow), which multiplies the number of waves
 // and leaves a longer LDS ring per row.  C = ring entries per row, SG = staging entries per row for
 // the fill; the launcher picks (R, C, SG) so that every wave of the grid is resident at once.
-template <int R, int C, int SG>
+template <int R, int C, int SG, bool PF>
 __global__ void __launch_bounds__(256) k_pass2_l2(const ColDesc* __restrict__ desc, float* __restrict__ vol, int W,
                                                   int H, int HW64, long nwaves, int* __restrict__ sv,
                                                   float* __restrict__ sf, float* __restrict__ sz) {
@@ -167,9 +167,10 @@ __global__ void __launch_bounds__(256) k_pass2_l2(const ColDesc* __restrict__ de
     __shared__ int r_v[C][NR];
     __shared__ float r_f[C][NR];
     __shared__ float r_z[C][NR];
-    __shared__ int g_v[SG][NR];
-    __shared__ float g_f[SG][NR];
-    __shared__ float g_z[SG][NR];
+    constexpr int G = PF ? 64 / R : 1;  // lane groups of a row that fill different parts of it
+    __shared__ int g_v[SG][NR * G];
+    __shared__ float g_f[SG][NR * G];
+    __shared__ float g_z[SG][NR * G];
     __shared__ uint4 dsc[4][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const long wid = (long)blockIdx.x * 4 + wave;
@@ -182,7 +183,6 @@ __global__ void __launch_bounds__(256) k_pass2_l2(const ColDesc* __restrict__ de
     const int bit = sub * R + (lane & (R - 1));  // row inside the chunk = bit of the seed word
     const int urow = wave * R + (lane & (R - 1));  // row inside the block (LDS column)
     const int y = c * 64 + bit;
-    const bool active = y < H && lane < R;
     const long gid = wid * R + (lane & (R - 1));  // scratch row
     const uint4* dp = reinterpret_cast<const uint4*>(desc + ((size_t)k * HW64 + c) * W);
     float* row = vol + (size_t)k * W * H + (y < H ? y : 0);  // element x at row[x * H]
@@ -275,11 +275,26 @@ __global__ void __launch_bounds__(256) k_pass2_l2(const ColDesc* __restrict__ de
     if (has_u) push_down(uv, uf, uz);
     push_down(tv, tf, tz);
     const int n_entries = cnt;
-    // ---- fill (imgproc.h:122-128).  The owner's base value img(v_k) is the already overwritten
-    // g[v_k] when v_k lies behind q, else the original f[v_k].  Entries are consumed in order from
-    // LDS (ring, or a 16-entry staging window refilled from HBM for the spilled part); g at the
-    // positions of the next two owners is captured when q passes them, which replaces almost
-    // every read-back of the image.
+    // ---- fill (imgproc.h:122-128).  The reference walks the pixels q = 0..W-1 with a pointer k
+    // into the stack (advance while z[k+1] < q) and writes (q - v[k])^2 + img(v[k]), reading
+    // img(v[k]) from the image it is overwriting: the original f[v_k] while v_k >= q, the already
+    // written g[v_k] afterwards.  z is strictly increasing along the stack, so entry k takes over at
+    // the first pixel above z_k and its addend is one constant: f[v_k] if z_k < v_k, else
+    // g[v_k] = (v_k - v_o)^2 + addend_o with o the owner of pixel v_k.
+    //
+    // Entries are consumed in order from LDS (ring, or an SG-entry staging window refilled from HBM
+    // for the spilled part) with a two-entry look-ahead.  g[v_k] is re-evaluated from the last three
+    // owners (same float expression), which removes almost every read-back of the image.
+    //
+    // PF: the 64 / R lane groups that ran the same row during the construction now fill different
+    // parts of it.  A part starts inside the pixels of an entry b with z_b < v_b (it took over at or
+    // before its own position, so its addend is f[v_b] and needs nothing from earlier pixels) and
+    // ends where the next group's part starts.  Every later entry k has v_k > v_b >= the pixel b
+    // took over at, so the g[v_k] it may need is a pixel owned by b or by a later entry of the
+    // part: it comes from the owner history or, on a miss, from a pixel this same lane has already
+    // written.  Groups never read each other's pixels.
+    const int grp = PF ? lane / R : 0;
+    const int srow = urow + NR * grp;  // staging column of this (row, lane group)
     int st0 = -SG;  // staging window holds entries [st0, st0 + SG)
     auto fetch = [&](int i, int& v, float& f, float& z) {
         if (i >= n_entries) { v = -1; f = 0.f; z = inf; return; }
@@ -298,26 +313,79 @@ __global__ void __launch_bounds__(256) k_pass2_l2(const ColDesc* __restrict__ de
                 lv[e] = sv[slot]; lf[e] = sf[slot]; lz[e] = sz[slot];
             }
 #pragma unroll
-            for (int e = 0; e < SG; ++e) { g_v[e][urow] = lv[e]; g_f[e][urow] = lf[e]; g_z[e][urow] = lz[e]; }
+            for (int e = 0; e < SG; ++e) { g_v[e][srow] = lv[e]; g_f[e][srow] = lf[e]; g_z[e][srow] = lz[e]; }
         }
-        v = g_v[i - st0][urow]; f = g_f[i - st0][urow]; z = g_z[i - st0][urow];
+        v = g_v[i - st0][srow]; f = g_f[i - st0][srow]; z = g_z[i - st0][srow];
     };
+    // random access to entry i (rare paths only; spilled entries are loaded and consumed in place)
+    auto entry_at = [&](int i, int& v, float& f, float& z) {
+        if (i >= base) {
+            const int r = i & (C - 1);
+            v = r_v[r][urow]; f = r_f[r][urow]; z = r_z[r][urow];
+        } else {
+            const size_t slot = (size_t)i * NT + gid;
+            const int a0 = sv[slot]; const float a1 = sf[slot], a2 = sz[slot];
+            asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "v"(a0));
+            asm volatile("v_mov_b32 %0, %1" : "=v"(f) : "v"(a1));
+            asm volatile("v_mov_b32 %0, %1" : "=v"(z) : "v"(a2));
+        }
+    };
+    // owner of pixel x: the last entry with z < x (z_0 = -inf, z strictly increasing)
+    auto owner_of = [&](float xf) {
+        int lo = 0, hi = n_entries - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            int mv; float mf, mz;
+            entry_at(mid, mv, mf, mz);
+            if (mz < xf) lo = mid; else hi = mid - 1;
+        }
+        return lo;
+    };
+    // Start of lane group g's part: g = 0 starts like the reference (pointer 0 at pixel 0); g >= G
+    // is the end of the row.  Else the part starts at pixel x = g * W / G if the owner of x takes
+    // over at or before its own position, otherwise where the next such entry takes over.
+    // Returns the entry, the first pixel, and the pixel at which the entry took over.
+    auto takeover = [&](float z) { return z < 0.f ? 0 : (!(z < (float)W) ? W : (int)floorf(z) + 1); };
+    auto part_start = [&](int g, int& k, int& q, int& since) {
+        if (g >= G) { k = n_entries; q = W; since = W; return; }
+        if (g == 0) { k = 0; q = 0; since = 0; return; }
+        const int x = min(g * ((W + G - 1) / G), W - 1);
+        k = owner_of((float)x);
+        int ev; float ef, ez;
+        entry_at(k, ev, ef, ez);
+        if (ez < (float)ev) { q = x; since = takeover(ez); return; }
+        for (++k; k < n_entries; ++k) {
+            entry_at(k, ev, ef, ez);
+            if (ez < (float)ev) { q = since = takeover(ez); return; }
+        }
+        q = since = W;
+    };
+    int kk = 0, q_begin = 0, q_end = W, k_next = n_entries, since0 = 0, since1 = 0;
+    if (PF) {
+        part_start(grp, kk, q_begin, since0);
+        part_start(grp + 1, k_next, q_end, since1);
+        q_begin = min(q_begin, q_end);
+    }
     int cv, av, bv;
     float cf, cz, af, az, bf, bz;
-    fetch(0, cv, cf, cz);
-    fetch(1, av, af, az);
-    fetch(2, bv, bf, bz);
-    int kk = 0;
+    fetch(kk, cv, cf, cz);
+    fetch(kk + 1, av, af, az);
+    fetch(kk + 2, bv, bf, bz);
     // Owner history: the current owner (cv, base_val) has owned pixels since ca; the two owners
     // before it are (pv, pbase) since pa and (p2v, p2base) since p2a.  When entry k takes over at a
     // pixel beyond its own position (!(z_k < v_k)) the reference reads the already written g[v_k]:
     // it is re-evaluated from the owner of pixel v_k in the history (same expression as the pixel
     // loop), or read back from the image if that owner is older than the history.
     float base_val = cf;
-    int ca = 0, pv = 0, pa = 0x7fffffff, p2v = 0, p2a = 0x7fffffff;
+    const int v_first = cv;
+    const float f_first = cf;
+    int ca = since0, pv = 0, pa = 0x7fffffff, p2v = 0, p2a = 0x7fffffff;
     float pbase = 0.f, p2base = 0.f;
-    for (int q = 0; q < W; ++q) {
-        while (az < (float)q) {
+    for (int it = 0; PF ? __any(q_begin + it < q_end) : it < W; ++it) {
+        const int q = q_begin + it;
+        const bool mine = !PF || q < q_end;
+        const float qf = (float)q;
+        while (mine && az < qf) {
             ++kk;
             const int nv_ = av;
             float nbase = af;
@@ -325,9 +393,11 @@ __global__ void __launch_bounds__(256) k_pass2_l2(const ColDesc* __restrict__ de
                 int ov = cv; float ob = base_val; bool found = nv_ >= ca;
                 if (!found && nv_ >= pa) { ov = pv; ob = pbase; found = true; }
                 if (!found && nv_ >= p2a) { ov = p2v; ob = p2base; found = true; }
+                // a pixel before this part's first pixel belongs to the entry the part started in
+                if (PF && !found && nv_ < q_begin) { ov = v_first; ob = f_first; found = true; }
                 if (found) {
-                    const unsigned dv = (unsigned)(nv_ - ov);
-                    nbase = ob + (float)(dv * dv);
+                    const float dv = (float)(nv_ - ov);  // dv * dv rounds like float(long(dv * dv)): same integer
+                    nbase = ob + dv * dv;
                 } else {
                     float t = 0.f;
                     if (y < H) t = row[(size_t)nv_ * H_];  // rare read-back, consumed inside the branch
@@ -342,8 +412,8 @@ __global__ void __launch_bounds__(256) k_pass2_l2(const ColDesc* __restrict__ de
             av = bv; af = bf; az = bz;
             fetch(kk + 2, bv, bf, bz);
         }
-        const unsigned dq = (unsigned)(q - cv);  // squared modulo 2^32: exact for |q - cv| < 2^16
-        if (active) row[(size_t)q * H_] = base_val + (float)(dq * dq);
+        const float dq = (float)(q - cv);  // dq * dq rounds like the reference's float(long(dq * dq))
+        if (mine && y < H && (PF || lane < R)) row[(size_t)q * H_] = base_val + dq * dq;
     }
 }
 
@@ -755,10 +825,11 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after) {
             // ring (fewer HBM round trips in the fill), large grids the short one (all waves resident).
             bool small_grid = nwaves <= 2048;
             if (const char* e = getenv("FDCM_K2_LEAN")) small_grid = atoi(e) == 0;  // tuning override
-#define FDCM_K2(RR, CC, SS) hipLaunchKernelGGL((k_pass2_l2<RR, CC, SS>), dim3(wblocks), dim3(256), 0, st, d_desc, vol, W, H, HW64, nwaves, sv, sf, sz)
-            if (R == 64) { if (small_grid) FDCM_K2(64, 16, 8); else FDCM_K2(64, 8, 4); }
-            else if (R == 32) { if (small_grid) FDCM_K2(32, 32, 16); else FDCM_K2(32, 16, 8); }
-            else { if (small_grid) FDCM_K2(16, 64, 16); else FDCM_K2(16, 32, 8); }
+#define FDCM_K2(RR, CC, SS, PP) hipLaunchKernelGGL((k_pass2_l2<RR, CC, SS, PP>), dim3(wblocks), dim3(256), 0, st, d_desc, vol, W, H, HW64, nwaves, sv, sf, sz)
+            static const bool no_pf = getenv("FDCM_K2_SERIAL_FILL") != nullptr;  // tuning override
+            if (R == 64) { if (small_grid) FDCM_K2(64, 16, 8, false); else FDCM_K2(64, 8, 4, false); }
+            else if (R == 32) { if (small_grid && !no_pf) FDCM_K2(32, 32, 8, true); else if (small_grid) FDCM_K2(32, 32, 16, false); else FDCM_K2(32, 16, 8, false); }
+            else { if (small_grid && !no_pf) FDCM_K2(16, 64, 4, true); else if (small_grid) FDCM_K2(16, 64, 16, false); else FDCM_K2(16, 32, 8, false); }
 #undef FDCM_K2
         }
     }
