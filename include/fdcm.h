@@ -127,7 +127,7 @@ int fdcm_search_device(const fdcm_featuremap* fm, const fdcm_templates* template
                        int64_t n_scene_lines, int64_t max_tmpl_lines, int64_t max_scene_lines, int optimizer,
                        int64_t batch_size, int32_t tmpl_index_base, fdcm_match* out_device, int64_t* n_out);
 int fdcm_search_last_timing(const fdcm_featuremap* fm, fdcm_search_timing* t);
-void fdcm_matches_free(fdcm_match* m);
+void fdcm_matches_free(fdcm_match* m); /* match arrays are pinned host buffers from a pool inside the library */
 
 /* ---- frame pipeline (throughput extension; the reference has no counterpart: its callers loop over frames
  *      and each search() blocks, python/src/matching.cpp:283-300).  One frame at the reference's sizes is

@@ -51,7 +51,7 @@ static void destroy(fdcm_featuremap* fm) {
     (void)hipSetDevice(fm->device);
     fm->vol.release(); fm->bitmap.release(); fm->coldesc.release(); fm->offtab.release(); fm->stack.release(); fm->plan.release(); fm->stage.release();
     fm->s_scene.release(); fm->s_pairs.release(); fm->s_records.release(); fm->s_flags.release(); fm->s_out.release(); fm->s_work.release();
-    fm->s_counter.release(); fm->s_stage.release(); fm->s_out_host.release();
+    fm->s_counter.release(); fm->s_stage.release();
     if (fm->timing.created)
         for (auto& e : fm->timing.ev) (void)hipEventDestroy(e);
     if (fm->stream) (void)hipStreamDestroy(fm->stream);
@@ -310,7 +310,7 @@ int fdcm_search_device(const fdcm_featuremap* fm, const fdcm_templates* template
         check_search_args(fm, templates, scene_lines, n_scene_lines, max_tmpl_lines, max_scene_lines, optimizer, batch_size);
         require(out_device && n_out, "null output");
         run_search(const_cast<fdcm_featuremap*>(fm), templates, scene_lines, n_scene_lines, max_tmpl_lines,
-                   max_scene_lines, optimizer, batch_size, tmpl_index_base, out_device, n_out);
+                   max_scene_lines, optimizer, batch_size, tmpl_index_base, out_device, nullptr, n_out);
     });
 }
 
@@ -322,11 +322,15 @@ int fdcm_search(const fdcm_featuremap* fm, const fdcm_templates* templates, cons
         require(out && n_out, "null output");
         fdcm_featuremap* f = const_cast<fdcm_featuremap*>(fm);
         *out = nullptr;
-        run_search(f, templates, scene_lines, n_scene_lines, max_tmpl_lines, max_scene_lines, optimizer, batch_size,
-                   tmpl_index_base, nullptr, n_out);
-        *out = (fdcm_match*)std::malloc(std::max<size_t>(1, (size_t)*n_out) * sizeof(fdcm_match));
-        if (!*out) throw std::string("out of host memory");
-        if (*n_out > 0) std::memcpy(*out, f->s_out_host.p, (size_t)*n_out * sizeof(fdcm_match));
+        try {
+            run_search(f, templates, scene_lines, n_scene_lines, max_tmpl_lines, max_scene_lines, optimizer, batch_size,
+                       tmpl_index_base, nullptr, out, n_out);
+        } catch (...) {
+            result_release(*out);
+            *out = nullptr;
+            throw;
+        }
+        if (!*out) *out = result_acquire(sizeof(fdcm_match));  // no candidates: an empty (non-null) array
     });
 }
 
@@ -337,7 +341,7 @@ int fdcm_search_last_timing(const fdcm_featuremap* fm, fdcm_search_timing* t) {
     });
 }
 
-void fdcm_matches_free(fdcm_match* m) { std::free(m); }
+void fdcm_matches_free(fdcm_match* m) { result_release(m); }
 
 int fdcm_filter_in_range(const float* lines, int64_t n_lines, const float center[2], float low_boundary,
                          float high_boundary, int64_t* out_indices, int64_t* n_out) {

@@ -4,6 +4,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <mutex>
+#include <unordered_map>
 
 #include "fdcm_internal.h"
 
@@ -178,6 +180,66 @@ void make_build_plan(const float* lines, int64_t n, int64_t depth, float coeff, 
         else if (std::abs(ry) == 1) { d.mode = 2; d.s = (int)(long)ry; d.r = rx; }
         plan.integral.push_back(d);
     }
+}
+
+
+// ---------------------------------------------------------------- result buffers
+// Match arrays handed to the caller (fdcm_search, fdcm_pipeline_wait) are pinned host buffers from
+// a small process-wide pool: the device-to-host copy lands in the buffer the caller receives (no
+// second copy), and a released buffer is reused instead of being unmapped (a fresh 1 MB malloc
+// costs ~250 page faults on first touch).  fdcm_matches_free returns a buffer to the pool.
+namespace {
+struct ResultPool {
+    std::mutex mu;
+    std::vector<std::pair<void*, size_t>> free_list;   // idle buffers
+    std::unordered_map<void*, size_t> capacity;        // every live buffer
+    static constexpr size_t kMaxIdle = 16;
+};
+ResultPool& result_pool() {
+    static ResultPool* p = new ResultPool();  // never destroyed: buffers may outlive static destructors
+    return *p;
+}
+}  // namespace
+
+fdcm_match* result_acquire(size_t bytes) {
+    bytes = std::max<size_t>(bytes, 64);
+    ResultPool& P = result_pool();
+    {
+        std::lock_guard<std::mutex> lk(P.mu);
+        size_t best = P.free_list.size();
+        for (size_t i = 0; i < P.free_list.size(); ++i)
+            if (P.free_list[i].second >= bytes && (best == P.free_list.size() || P.free_list[i].second < P.free_list[best].second))
+                best = i;
+        if (best != P.free_list.size()) {
+            void* p = P.free_list[best].first;
+            P.free_list.erase(P.free_list.begin() + (long)best);
+            return (fdcm_match*)p;
+        }
+    }
+    const size_t cap = (bytes + (1u << 16) - 1) & ~(size_t)((1u << 16) - 1);
+    void* p = nullptr;
+    FDCM_HIP(hipHostMalloc(&p, cap, hipHostMallocPortable));
+    std::lock_guard<std::mutex> lk(P.mu);
+    P.capacity[p] = cap;
+    return (fdcm_match*)p;
+}
+
+void result_release(fdcm_match* m) {
+    if (!m) return;
+    ResultPool& P = result_pool();
+    void* victim = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(P.mu);
+        auto it = P.capacity.find((void*)m);
+        if (it == P.capacity.end()) return;  // not ours: ignore rather than corrupt the heap
+        if (P.free_list.size() < ResultPool::kMaxIdle) {
+            P.free_list.emplace_back((void*)m, it->second);
+        } else {
+            victim = (void*)m;
+            P.capacity.erase(it);
+        }
+    }
+    if (victim) (void)hipHostFree(victim);
 }
 
 }  // namespace fdcm

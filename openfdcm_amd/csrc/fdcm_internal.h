@@ -117,7 +117,6 @@ struct fdcm_featuremap {
     fdcm::DevBuf s_work;    // search work list: valid pairs grouped by scene line
     fdcm::DevBuf s_counter;
     fdcm::PinnedBuf s_stage;
-    fdcm::PinnedBuf s_out_host;  // pinned landing area of the compacted matches (host-output searches)
     fdcm::Timing timing;
     fdcm_build_timing last_build = {};
     fdcm_search_timing last_search = {};
@@ -139,5 +138,9 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after);
 // implemented in fdcm_search.hip
 int64_t search_capacity(const fdcm_templates* t, int64_t n_scene, int64_t maxT, int64_t maxS);
 void run_search(fdcm_featuremap* fm, const fdcm_templates* t, const float* scene, int64_t n_scene, int64_t maxT,
-                int64_t maxS, int optimizer, int64_t batch, int32_t base, fdcm_match* out_device, int64_t* n_out);
+                int64_t maxS, int optimizer, int64_t batch, int32_t base, fdcm_match* out_device, fdcm_match** out_host,
+                int64_t* n_out);
+// pooled pinned host buffers for match arrays returned to the caller (fdcm_host.cpp)
+fdcm_match* result_acquire(size_t bytes);
+void result_release(fdcm_match* m);
 }  // namespace fdcm

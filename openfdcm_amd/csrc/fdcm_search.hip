@@ -529,7 +529,8 @@ int64_t search_capacity(const fdcm_templates* t, int64_t n_scene, int64_t maxT, 
 }
 
 void run_search(fdcm_featuremap* fm, const fdcm_templates* t, const float* scene, int64_t n_scene, int64_t maxT,
-                int64_t maxS, int optimizer, int64_t batch, int32_t base, fdcm_match* out_device, int64_t* n_out) {
+                int64_t maxS, int optimizer, int64_t batch, int32_t base, fdcm_match* out_device, fdcm_match** out_host,
+                int64_t* n_out) {
     const auto t0 = std::chrono::steady_clock::now();
     *n_out = 0;
     fm->last_search = fdcm_search_timing{};
@@ -656,11 +657,12 @@ void run_search(fdcm_featuremap* fm, const fdcm_templates* t, const float* scene
     FDCM_HIP(hipGetLastError());
     unsigned long long hc[3] = {0, 0, 0};
     FDCM_HIP(hipMemcpyAsync(hc, fm->s_counter.p, sizeof hc, hipMemcpyDeviceToHost, st));
-    if (!out_device && ncand > 0) {
+    if (out_host) {
         // host-output search: the count is not known on the host yet, so the whole candidate capacity
-        // (32 B per candidate) goes to pinned memory in the same stream: one synchronisation per search
-        fm->s_out_host.reserve((size_t)ncand * sizeof(fdcm_match));
-        FDCM_HIP(hipMemcpyAsync(fm->s_out_host.p, dst, (size_t)ncand * sizeof(fdcm_match), hipMemcpyDeviceToHost, st));
+        // (32 B per candidate) goes to the caller's (pooled, pinned) buffer in the same stream: one
+        // synchronisation per search and no second copy
+        *out_host = result_acquire((size_t)ncand * sizeof(fdcm_match));
+        FDCM_HIP(hipMemcpyAsync(*out_host, dst, (size_t)ncand * sizeof(fdcm_match), hipMemcpyDeviceToHost, st));
     }
     FDCM_HIP(hipStreamSynchronize(st));
     *n_out = (int64_t)hc[2];
