@@ -163,6 +163,16 @@ int fdcm_penalize(int penalty, float tau, fdcm_match* matches, int64_t n, const 
                   int64_t n_templates);
 int fdcm_sort_matches(fdcm_match* matches, int64_t n);
 
+/* ---- device tail: penalize + sort_matches + "the k best" on matches resident in HBM (the reference's callers do
+ *      penalize(), sort_matches() and slice: README.md:71-72, python/src/matching.cpp:291-307).  matches_device:
+ *      a buffer filled by fdcm_search_device (n records), or NULL for the matches of the last fdcm_search on
+ *      `fm`.  penalty: FDCM_DEFAULT_PENALTY, FDCM_EXPONENTIAL_PENALTY (tau) or -1 for none.  Returns min(k, n)
+ *      records in ascending penalised score, ties in positional order (the reference's std::sort leaves ties
+ *      unspecified); scores are the reference's bits (denominators from the host libm, IEEE division on the
+ *      device).  Release with fdcm_matches_free.  In sharded runs each rank sends its k best instead of all. ---- */
+int fdcm_topk(fdcm_featuremap* fm, const fdcm_templates* templates, const fdcm_match* matches_device, int64_t n,
+              int32_t tmpl_index_base, int penalty, float tau, int64_t k, fdcm_match** out, int64_t* n_out);
+
 /* ---- host-side self checks (no GPU needed) ---- */
 /* Compare the device-portable atanf restatement with this machine's libm atanf over the float
  * bit patterns first, first+stride, ... (count values); returns the number of mismatches. */

@@ -64,6 +64,7 @@ SYMBOLS = [
                                      _vp, _i64p]),
     ("fdcm_search_last_timing", C.c_int, [_vp, C.POINTER(SearchTiming)]),
     ("fdcm_matches_free", None, [_vp]),
+    ("fdcm_topk", C.c_int, [_vp, _vp, _vp, C.c_int64, C.c_int32, C.c_int, C.c_float, C.c_int64, C.POINTER(_vp), _i64p]),
     ("fdcm_pipeline_create", C.c_int, [C.c_int64, C.c_float, C.c_float, C.c_int, _vp, C.c_int64, C.c_int64, C.c_int,
                                        C.c_int64, C.c_int32, C.c_int, C.POINTER(_vp)]),
     ("fdcm_pipeline_submit", C.c_int, [_vp, _fp, C.c_int64, _vp, _i64p]),

@@ -50,7 +50,7 @@ static void destroy(fdcm_featuremap* fm) {
     if (!fm) return;
     (void)hipSetDevice(fm->device);
     fm->vol.release(); fm->bitmap.release(); fm->coldesc.release(); fm->offtab.release(); fm->stack.release(); fm->plan.release(); fm->stage.release();
-    fm->s_scene.release(); fm->s_pairs.release(); fm->s_records.release(); fm->s_flags.release(); fm->s_out.release(); fm->s_work.release();
+    fm->s_scene.release(); fm->s_pairs.release(); fm->s_records.release(); fm->s_flags.release(); fm->s_out.release(); fm->s_work.release(); fm->s_tail.release();
     fm->s_counter.release(); fm->s_stage.release();
     if (fm->timing.created)
         for (auto& e : fm->timing.ev) (void)hipEventDestroy(e);
@@ -331,6 +331,29 @@ int fdcm_search(const fdcm_featuremap* fm, const fdcm_templates* templates, cons
             throw;
         }
         if (!*out) *out = result_acquire(sizeof(fdcm_match));  // no candidates: an empty (non-null) array
+        f->last_n_out = *n_out;
+    });
+}
+
+int fdcm_topk(fdcm_featuremap* fm, const fdcm_templates* templates, const fdcm_match* matches_device, int64_t n,
+              int32_t tmpl_index_base, int penalty, float tau, int64_t k, fdcm_match** out, int64_t* n_out) {
+    return guarded([&] {
+        require(fm && templates && out && n_out, "null argument");
+        require(penalty >= -1 && penalty <= FDCM_EXPONENTIAL_PENALTY, "unknown penalty");
+        require(fm->device == templates->device, "featuremap and templates live on different devices");
+        require(k >= 0, "k must be >= 0");
+        if (!matches_device) {  // the matches of the last fdcm_search on this handle
+            matches_device = fm->s_out.as<fdcm_match>();
+            n = fm->last_n_out;
+        }
+        require(n >= 0 && (n == 0 || matches_device), "bad matches");
+        try {
+            run_topk(fm, templates, matches_device, n, tmpl_index_base, penalty, tau, k, out, n_out);
+        } catch (...) {
+            result_release(*out);
+            *out = nullptr;
+            throw;
+        }
     });
 }
 

@@ -115,6 +115,8 @@ struct fdcm_featuremap {
     fdcm::DevBuf s_flags;   // per-candidate valid flag + scan scratch
     fdcm::DevBuf s_out;     // compacted matches
     fdcm::DevBuf s_work;    // search work list: valid pairs grouped by scene line
+    fdcm::DevBuf s_tail;    // device tail (penalise + sort + top k) workspace
+    int64_t last_n_out = 0; // matches of the last host-output search, still in s_out
     fdcm::DevBuf s_counter;
     fdcm::PinnedBuf s_stage;
     fdcm::Timing timing;
@@ -140,6 +142,9 @@ int64_t search_capacity(const fdcm_templates* t, int64_t n_scene, int64_t maxT, 
 void run_search(fdcm_featuremap* fm, const fdcm_templates* t, const float* scene, int64_t n_scene, int64_t maxT,
                 int64_t maxS, int optimizer, int64_t batch, int32_t base, fdcm_match* out_device, fdcm_match** out_host,
                 int64_t* n_out);
+// implemented in fdcm_tail.hip
+void run_topk(fdcm_featuremap* fm, const fdcm_templates* t, const fdcm_match* matches_device, int64_t n, int32_t base,
+              int penalty, float tau, int64_t k, fdcm_match** out, int64_t* n_out);
 // pooled pinned host buffers for match arrays returned to the caller (fdcm_host.cpp)
 fdcm_match* result_acquire(size_t bytes);
 void result_release(fdcm_match* m);

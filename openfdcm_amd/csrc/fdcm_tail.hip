@@ -1,0 +1,99 @@
+// fdcm_tail.hip -- the step after the search in every caller of the reference (README.md:71-72,
+// python/src/matching.cpp:291-307): penalize<Default/ExponentialPenalty> + sort_matches + "take the
+// best k", on the raw matches while they are still in HBM, so that only k records leave the GPU
+// (and, in sharded runs, only k records per rank cross xGMI).
+//
+// The penalty's denominator per template, max(len, 1e-6) or pow(max(len, 1e-6), tau)
+// (defaultpenalty.cpp:37-41, exponentialpenalty.cpp:42-46), is computed on the host with the host's
+// libm exactly as the reference does; the device only divides (IEEE, correctly rounded), so the
+// penalised scores are the reference's bits.  Order: ascending score, ties in positional order
+// (the reference's std::sort leaves ties unspecified): a stable radix sort of (score, position).
+#include <hipcub/hipcub.hpp>
+
+#include <cmath>
+#include <cstring>
+
+#include "fdcm_internal.h"
+
+namespace fdcm {
+
+// total order on float bit patterns as unsigned integers (-0 < +0, NaNs at the ends)
+__device__ __forceinline__ unsigned ordered_key(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__global__ void k_tail_keys(const fdcm_match* __restrict__ m, long long n, const float* __restrict__ denom, int base,
+                            int T, unsigned* __restrict__ keys, unsigned* __restrict__ idx, float* __restrict__ pscore) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = m[i].score;
+    if (denom) {
+        const int t = m[i].tmpl_idx - base;
+        s = (t >= 0 && t < T) ? s / denom[t] : __uint_as_float(0x7fc00000u);  // out of range: NaN, sorts last
+    }
+    pscore[i] = s;
+    keys[i] = ordered_key(s);
+    idx[i] = (unsigned)i;
+}
+
+__global__ void k_tail_gather(const fdcm_match* __restrict__ m, const unsigned* __restrict__ idx,
+                              const float* __restrict__ pscore, long long k, fdcm_match* __restrict__ out) {
+    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= k) return;
+    fdcm_match r = m[idx[j]];
+    r.score = pscore[idx[j]];
+    out[j] = r;
+}
+
+void run_topk(fdcm_featuremap* fm, const fdcm_templates* t, const fdcm_match* matches_device, int64_t n, int32_t base,
+              int penalty, float tau, int64_t k, fdcm_match** out, int64_t* n_out) {
+    *out = nullptr;
+    *n_out = 0;
+    FDCM_HIP(hipSetDevice(fm->device));
+    if (!fm->stream) FDCM_HIP(hipStreamCreateWithFlags(&fm->stream, hipStreamNonBlocking));
+    hipStream_t st = fm->stream;
+    k = std::min<int64_t>(std::max<int64_t>(k, 0), n);
+    *out = result_acquire(std::max<size_t>(1, (size_t)k) * sizeof(fdcm_match));
+    if (k == 0) return;
+    if (n > 0x7fffffffll) throw std::string("more than 2^31 matches are not supported by the device tail");
+    // ---- denominators on the host (getTemplateLengths + the penalty's formula), uploaded through pinned staging
+    const bool pen = penalty >= 0;
+    const size_t a256 = 255;
+    const size_t o_den = 0, o_keys = ((size_t)t->T * 4 + a256) & ~a256, o_keys2 = o_keys + (((size_t)n * 4 + a256) & ~a256),
+                 o_idx = o_keys2 + (((size_t)n * 4 + a256) & ~a256), o_idx2 = o_idx + (((size_t)n * 4 + a256) & ~a256),
+                 o_ps = o_idx2 + (((size_t)n * 4 + a256) & ~a256), o_out = o_ps + (((size_t)n * 4 + a256) & ~a256),
+                 o_tmp = o_out + (((size_t)k * sizeof(fdcm_match) + a256) & ~a256);
+    size_t tmp_bytes = 0;
+    FDCM_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, (const unsigned*)nullptr, (unsigned*)nullptr,
+                                                (const unsigned*)nullptr, (unsigned*)nullptr, (int)n, 0, 32, st));
+    fm->s_tail.reserve(o_tmp + tmp_bytes + 256);
+    char* d = (char*)fm->s_tail.p;
+    if (pen) {
+        std::vector<float> len((size_t)t->T);
+        if (t->T) {
+            if (fdcm_templates_lengths(t, len.data()) != FDCM_OK) throw std::string(fdcm_last_error());
+        }
+        fm->s_stage.reserve(std::max<size_t>(16, (size_t)t->T * 4));
+        float* hd = (float*)fm->s_stage.p;
+        for (int64_t i = 0; i < t->T; ++i) {
+            const float l = std::max(len[(size_t)i], 1e-6f);
+            hd[i] = penalty == FDCM_DEFAULT_PENALTY ? l : std::pow(l, tau);
+        }
+        if (t->T) FDCM_HIP(hipMemcpyAsync(d + o_den, hd, (size_t)t->T * 4, hipMemcpyHostToDevice, st));
+    }
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(k_tail_keys, dim3(nb), dim3(256), 0, st, matches_device, (long long)n,
+                       pen ? (const float*)(d + o_den) : nullptr, (int)base, (int)t->T, (unsigned*)(d + o_keys),
+                       (unsigned*)(d + o_idx), (float*)(d + o_ps));
+    FDCM_HIP(hipcub::DeviceRadixSort::SortPairs(d + o_tmp, tmp_bytes, (const unsigned*)(d + o_keys), (unsigned*)(d + o_keys2),
+                                                (const unsigned*)(d + o_idx), (unsigned*)(d + o_idx2), (int)n, 0, 32, st));
+    hipLaunchKernelGGL(k_tail_gather, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, st, matches_device,
+                       (const unsigned*)(d + o_idx2), (const float*)(d + o_ps), (long long)k, (fdcm_match*)(d + o_out));
+    FDCM_HIP(hipGetLastError());
+    FDCM_HIP(hipMemcpyAsync(*out, d + o_out, (size_t)k * sizeof(fdcm_match), hipMemcpyDeviceToHost, st));
+    FDCM_HIP(hipStreamSynchronize(st));
+    *n_out = k;
+}
+
+}  // namespace fdcm

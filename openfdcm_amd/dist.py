@@ -70,11 +70,44 @@ class ShardedSearcher:
                         self._buf.data_ptr())
         return self._buf[: n * RECORD_BYTES]
 
+    def search_topk(self, fm, scene, max_tmpl_lines, max_scene_lines, optimizer, batch_size, k, penalty=None, tau=1.0,
+                    group=None):
+        """Sharded search + device tail: every rank penalises, sorts and keeps its k best in HBM
+        (fdcm_topk), and only those k records per rank are gathered.  Returns the global k best on rank 0."""
+        from .engine import topk
+        local = self.search_local(fm, scene, max_tmpl_lines, max_scene_lines, optimizer, batch_size)
+        n = local.numel() // RECORD_BYTES
+        best = topk(fm, self.tset, k, penalty, tau, tmpl_index_base=self.begin, device_ptr=self._buf.data_ptr(), n=n)
+        if self.world == 1:
+            return best
+        return gather_topk(best, k, self.device, group=group)
+
     def search(self, fm, scene, max_tmpl_lines, max_scene_lines, optimizer, batch_size, group=None):
         local = self.search_local(fm, scene, max_tmpl_lines, max_scene_lines, optimizer, batch_size)
         if self.world == 1:
             return local.cpu().numpy().view(MATCH_DTYPE)
         return gather_matches(local, self.device, group=group)
+
+
+def merge_topk(parts, k):
+    """Merge per-rank k-best lists (each ascending by score, ties in positional order) given in rank order:
+    a stable sort by score keeps ties in (rank, position) = global positional order."""
+    allm = np.concatenate(parts) if parts else np.zeros(0, dtype=MATCH_DTYPE)
+    order = np.argsort(allm["score"], kind="stable")
+    return allm[order[:k]]
+
+
+def gather_topk(local_topk, k, device, group=None, dst=0):
+    """local_topk: this rank's k best (structured numpy array, <= k records).  Returns the global k best on
+    rank `dst` (None elsewhere): k records per rank cross the links instead of every match."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    buf = torch.from_numpy(np.ascontiguousarray(local_topk).view(np.uint8).copy()).to(device)
+    res = gather_matches(buf, device, group=group, dst=dst)
+    if rank != dst:
+        return None
+    # gather_matches concatenates the lists in rank order, which is what the stable merge needs
+    return merge_topk([res], k)
 
 
 class ShardedPipeline:

@@ -215,3 +215,17 @@ class FramePipeline:
             self.close()
         except Exception:
             pass
+
+
+def topk(fm, templates, k, penalty=None, tau=1.0, tmpl_index_base=0, device_ptr=None, n=0):
+    """penalize + sort_matches + [:k] on the device (include/fdcm.h, "device tail").
+
+    Works on the raw matches of the last search_raw() on `fm`, or on a device buffer filled by
+    search_into() (`device_ptr`, `n` records).  penalty: None, capi.DEFAULT_PENALTY or
+    capi.EXPONENTIAL_PENALTY (with tau).  Returns a structured array (capi.MATCH_DTYPE) of min(k, n)
+    records, ascending penalised score, ties in positional order."""
+    out, n_out = C.c_void_p(), C.c_int64()
+    capi.check(capi.lib().fdcm_topk(fm._h, templates._h, C.c_void_p(device_ptr) if device_ptr else None, int(n),
+                                    int(tmpl_index_base), -1 if penalty is None else int(penalty), float(tau), int(k),
+                                    C.byref(out), C.byref(n_out)))
+    return _adopt_matches(out, n_out.value)

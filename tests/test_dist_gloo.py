@@ -140,3 +140,40 @@ def test_sharded_pipeline_world2(tmp_path):
     out = str(tmp_path / "n.npy")
     mp.spawn(_pipe_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     assert int(np.load(out)[0]) == 5
+
+
+def _topk_worker(rank, world, port, out_path):
+    from oracle import oracle as O
+    from openfdcm_amd.dist import gather_topk
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        S = 128
+        scene = synthetic.scene(S, 30, 5)
+        tmpls = synthetic.templates(7, 9, S, 6)
+        fm = O.build(scene, depth=12, coeff=5.0, padding=1.0)
+        b, e = shard_range(len(tmpls), rank, world)
+        local = O.search(fm, tmpls[b:e], scene, 3, 3, kind=O.BATCH_OPTIMIZE, batch=10).astype(MATCH_DTYPE)
+        local["tmpl_idx"] += b
+        local["score"] = np.round(local["score"], -1)  # force ties across ranks
+        k = 9
+        mine = local[np.argsort(local["score"], kind="stable")[:k]]  # what fdcm_topk returns per rank
+        res = gather_topk(mine, k, torch.device("cpu"))
+        if rank == 0:
+            full = O.search(fm, tmpls, scene, 3, 3, kind=O.BATCH_OPTIMIZE, batch=10).astype(MATCH_DTYPE)
+            full["score"] = np.round(full["score"], -1)
+            want = full[np.argsort(full["score"], kind="stable")[:k]]
+            assert res.tobytes() == want.tobytes()
+            np.save(out_path, np.array([len(res)]))
+        else:
+            assert res is None
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_topk_world2(tmp_path):
+    """k best per rank, gathered and merged, equal the k best of the whole list (ties in positional order)."""
+    out = str(tmp_path / "n.npy")
+    mp.spawn(_topk_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert int(np.load(out)[0]) == 9

@@ -343,3 +343,43 @@ def test_config5_sampled_slices(amd):
     for k in sorted(set(np.linspace(0, dev.depth - 1, 7).astype(int))):
         a, b = dev.slice(int(k)), orc.slice(int(k))
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"config 5 slice {k}"
+
+
+# ---------------------------------------------------------------- device tail (include/fdcm.h, fdcm_topk)
+@pytest.mark.parametrize("penalty,tau", [(None, 1.0), (0, 1.0), (1, 1.5), (1, 0.7)])
+def test_device_topk_equals_penalize_sort_slice(amd, penalty, tau):
+    """fdcm_topk == penalize() + stable sort by score + [:k] on the host, bit for bit."""
+    import ctypes as C
+    import torch
+    from openfdcm_amd import synthetic, _capi
+    from openfdcm_amd.engine import DeviceFeatureMap, DeviceTemplates, search_raw, search_into, topk
+    S = 256
+    scene = synthetic.scene(S, 60, 11)
+    tmpls = synthetic.templates(40, 13, S, 12) + synthetic.templates(10, 32, S, 13) + synthetic.templates(5, 3, S, 14)
+    fm = DeviceFeatureMap.build(scene, depth=30, coeff=5.0, padding=1.0, distance=O.L2)
+    tset = DeviceTemplates(tmpls)
+    raw = search_raw(fm, tset, scene, 4, 4, _capi.BATCH_OPTIMIZE, 10, 7)  # tmpl_index_base 7
+    assert len(raw) > 500
+
+    def host_tail(k):
+        rec = np.array(raw, copy=True)
+        if penalty is not None:
+            rec["tmpl_idx"] -= 7
+            lens = tset.lengths()
+            _capi.check(_capi.lib().fdcm_penalize(penalty, tau, C.c_void_p(rec.ctypes.data), len(rec), _capi.fptr(lens),
+                                                  len(lens)))
+            rec["tmpl_idx"] += 7
+        return rec[np.argsort(rec["score"], kind="stable")[:k]]
+
+    for k in (1, 10, 100, len(raw), len(raw) + 50):
+        got = topk(fm, tset, k, penalty, tau, tmpl_index_base=7)
+        want = host_tail(k)
+        assert got.tobytes() == want.tobytes(), (penalty, tau, k)
+    # the same from a caller-owned device buffer (the sharded path)
+    cap = tset.capacity(60, 4, 4)
+    buf = torch.empty(cap * 32, dtype=torch.uint8, device="cuda")
+    n = search_into(fm, tset, scene, 4, 4, _capi.BATCH_OPTIMIZE, 10, 7, buf.data_ptr())
+    assert n == len(raw)
+    got = topk(fm, tset, 25, penalty, tau, tmpl_index_base=7, device_ptr=buf.data_ptr(), n=n)
+    assert got.tobytes() == host_tail(25).tobytes()
+    assert len(topk(fm, tset, 0, penalty, tau, tmpl_index_base=7)) == 0
