@@ -263,12 +263,28 @@ __global__ void __launch_bounds__(256) k_pass2_l2(const ColDesc* __restrict__ de
             tf = column_value<true>(((unsigned long long)d0.y << 32) | d0.x, (int)d0.z, (int)d0.w, bit, y);
             todo &= ~1ull;
         }
+        // The 64 / R lane groups of a row would compute the same pass-1 value; instead group g takes
+        // the (g+1)-th pending column, and the values are handed round with lane permutes (issued one
+        // column ahead), so the bit-scan runs once per 64 / R columns.
+        constexpr int GC = 64 / R;
+        const int grp_c = lane / R, lane_r = lane & (R - 1);
         while (todo) {
-            const int j = __ffsll((long long)todo) - 1;
-            todo &= todo - 1ull;
-            const uint4 dj = dsc[wave][j];  // LDS broadcast
-            const float fq = column_value<true>(((unsigned long long)dj.y << 32) | dj.x, (int)dj.z, (int)dj.w, bit, y);
-            process_column(q0 + j, fq);
+            unsigned long long tm = todo;
+#pragma unroll
+            for (int i = 0; i + 1 < GC; ++i)
+                if (i < grp_c) tm &= tm - 1ull;
+            const int jm = tm ? __ffsll((long long)tm) - 1 : 0;
+            const uint4 dj = dsc[wave][jm];
+            const float fmine = column_value<true>(((unsigned long long)dj.y << 32) | dj.x, (int)dj.z, (int)dj.w, bit, y);
+            float fq = GC > 1 ? __shfl(fmine, lane_r) : fmine;
+#pragma unroll 1
+            for (int cc = 0; cc < GC && todo; ++cc) {
+                const int j = __ffsll((long long)todo) - 1;
+                todo &= todo - 1ull;
+                const float fq_next = (GC > 1 && cc + 1 < GC) ? __shfl(fmine, lane_r + R * (cc + 1)) : 0.f;
+                process_column(q0 + j, fq);
+                fq = fq_next;
+            }
         }
     }
     // ---- the register pair joins the ring: entries [base, n) are in LDS, [0, base) in HBM
