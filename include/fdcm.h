@@ -12,7 +12,10 @@
  * fdcm_last_error() returns a thread-local message.  No exception crosses the boundary.  Inputs
  * are caller-owned host buffers (plain pointers + counts) unless a parameter says "device".
  * Outputs allocated by the library are released with the matching *_free.  Calls block until the
- * result is complete and are safe to make with the Python GIL released.  Handles are
+ * result is complete and are safe to make with the Python GIL released; the one exception is
+ * fdcm_featuremap_build / _rebuild, which return once the build is queued on the handle's HIP stream
+ * (every later call on the handle that touches the volume -- search, slice, device_volume, timing,
+ * free -- is ordered behind it or waits for it, so a kernel failure is reported by that call).  Handles are
  * thread-compatible (one caller at a time per handle).
  *
  * Line arrays are the reference's LineArray (math.h:66): 4 x N float32, column-major, i.e. N

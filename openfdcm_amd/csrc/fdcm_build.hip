@@ -774,6 +774,7 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after) {
     FDCM_HIP(hipSetDevice(fm->device));
     if (!fm->stream) FDCM_HIP(hipStreamCreateWithFlags(&fm->stream, hipStreamNonBlocking));
     ensure_timing(fm);
+    finish_build(fm);  // the previous build's staging and events are reused below
     hipStream_t st = fm->stream;
     fm->W = plan.W; fm->H = plan.H; fm->m = plan.m; fm->tx = plan.tx; fm->ty = plan.ty;
     fm->keys = plan.keys;
@@ -817,6 +818,7 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after) {
     float* vol = fm->vol.as<float>();
     hipEvent_t* ev = fm->timing.ev;
 
+    fm->build_host_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     FDCM_HIP(hipEventRecord(ev[0], st));
     FDCM_HIP(hipMemsetAsync(fm->bitmap.p, 0, (size_t)ncols * HW64 * 8, st));
     if (fm->n_raster > 0)
@@ -883,15 +885,24 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after) {
     }
     FDCM_HIP(hipEventRecord(ev[5], st));
     FDCM_HIP(hipGetLastError());
-    FDCM_HIP(hipStreamSynchronize(st));
-    const auto t1 = std::chrono::steady_clock::now();
+    fm->build_pending = true;  // not waited for here: see finish_build
+}
+
+void finish_build(fdcm_featuremap* fm) {
+    if (!fm->build_pending) return;
+    fm->build_pending = false;
+    FDCM_HIP(hipSetDevice(fm->device));
+    FDCM_HIP(hipStreamSynchronize(fm->stream));
+    hipEvent_t* ev = fm->timing.ev;
     fdcm_build_timing& bt = fm->last_build;
-    bt.total_ms = std::chrono::duration<float, std::milli>(t1 - t0).count();
     FDCM_HIP(hipEventElapsedTime(&bt.seeds_ms, ev[0], ev[1]));
     FDCM_HIP(hipEventElapsedTime(&bt.pass1_ms, ev[1], ev[2]));
     FDCM_HIP(hipEventElapsedTime(&bt.pass2_ms, ev[2], ev[3]));
     FDCM_HIP(hipEventElapsedTime(&bt.propagate_ms, ev[3], ev[4]));
     FDCM_HIP(hipEventElapsedTime(&bt.integral_ms, ev[4], ev[5]));
+    float span = 0.f;
+    FDCM_HIP(hipEventElapsedTime(&span, ev[0], ev[5]));
+    bt.total_ms = fm->build_host_ms + span;  // host preparation + the kernels' span on the device
 }
 
 }  // namespace fdcm

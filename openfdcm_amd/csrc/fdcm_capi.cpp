@@ -49,6 +49,7 @@ static void upload_keys_only(fdcm_featuremap* fm) {
 static void destroy(fdcm_featuremap* fm) {
     if (!fm) return;
     (void)hipSetDevice(fm->device);
+    if (fm->stream) (void)hipStreamSynchronize(fm->stream);
     fm->vol.release(); fm->bitmap.release(); fm->coldesc.release(); fm->offtab.release(); fm->stack.release(); fm->plan.release(); fm->stage.release();
     fm->s_scene.release(); fm->s_pairs.release(); fm->s_records.release(); fm->s_flags.release(); fm->s_out.release(); fm->s_work.release(); fm->s_tail.release();
     fm->s_counter.release(); fm->s_stage.release();
@@ -141,6 +142,7 @@ int fdcm_featuremap_slice(const fdcm_featuremap* fm, int64_t k, float* out_host)
     return guarded([&] {
         require(fm && out_host, "null argument");
         require(k >= 0 && k < fm->m, "slice index out of range");
+        finish_build(const_cast<fdcm_featuremap*>(fm));
         FDCM_HIP(hipSetDevice(fm->device));
         const size_t npix = (size_t)fm->W * fm->H;
         FDCM_HIP(hipMemcpy(out_host, fm->vol.as<float>() + (size_t)k * npix, npix * sizeof(float), hipMemcpyDeviceToHost));
@@ -150,6 +152,7 @@ int fdcm_featuremap_slice(const fdcm_featuremap* fm, int64_t k, float* out_host)
 int fdcm_featuremap_device_volume(const fdcm_featuremap* fm, const float** device_ptr) {
     return guarded([&] {
         require(fm && device_ptr, "null argument");
+        finish_build(const_cast<fdcm_featuremap*>(fm));  // the caller may read it from any stream
         *device_ptr = fm->vol.as<float>();
     });
 }
@@ -157,6 +160,7 @@ int fdcm_featuremap_device_volume(const fdcm_featuremap* fm, const float** devic
 int fdcm_featuremap_last_timing(const fdcm_featuremap* fm, fdcm_build_timing* t) {
     return guarded([&] {
         require(fm && t, "null argument");
+        finish_build(const_cast<fdcm_featuremap*>(fm));
         *t = fm->last_build;
     });
 }

@@ -94,6 +94,8 @@ struct fdcm_featuremap {
     int64_t depth_param = 0;
     float coeff = 0, padding = 0;
     int distance = 0;
+    bool build_pending = false;  // the last build is queued on `stream` but has not been waited for
+    float build_host_ms = 0.f;   // host time of that call up to its first kernel launch
     // geometry
     int64_t W = 0, H = 0, m = 0;
     float tx = 0, ty = 0;
@@ -137,6 +139,9 @@ struct fdcm_templates {
 namespace fdcm {
 // implemented in fdcm_build.hip
 void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after);
+// Waits for a queued build (if any) and fills fm->last_build.  run_build only queues the kernels: the search
+// that follows is ordered behind them on the same stream and its host-side preparation runs meanwhile.
+void finish_build(fdcm_featuremap* fm);
 // implemented in fdcm_search.hip
 int64_t search_capacity(const fdcm_templates* t, int64_t n_scene, int64_t maxT, int64_t maxS);
 void run_search(fdcm_featuremap* fm, const fdcm_templates* t, const float* scene, int64_t n_scene, int64_t maxT,

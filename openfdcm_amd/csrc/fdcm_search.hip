@@ -665,6 +665,7 @@ void run_search(fdcm_featuremap* fm, const fdcm_templates* t, const float* scene
         FDCM_HIP(hipMemcpyAsync(*out_host, dst, (size_t)ncand * sizeof(fdcm_match), hipMemcpyDeviceToHost, st));
     }
     FDCM_HIP(hipStreamSynchronize(st));
+    finish_build(fm);  // a build queued before this search is complete as well: collect its timings
     *n_out = (int64_t)hc[2];
     fm->last_search.evaluations = (int64_t)hc[0];
     FDCM_HIP(hipEventElapsedTime(&fm->last_search.kernel_ms, ev[6], ev[7]));
