@@ -62,7 +62,7 @@ typedef struct fdcm_featuremap_info {
 
 /* Per-stage device times of the last build, in milliseconds (HIP events on the build stream). */
 typedef struct fdcm_build_timing {
-    float total_ms;     /* host prep + upload + all kernels, host wall clock */
+    float total_ms;     /* host preparation + the kernels' span on the device */
     float seeds_ms;     /* K0: rasterise scene lines into the seed bitmap */
     float pass1_ms;     /* K1: 1-D distance along y */
     float pass2_ms;     /* K2: in-place lower-envelope pass along x (L2/L2^2) or L1 sweeps */
@@ -71,7 +71,7 @@ typedef struct fdcm_build_timing {
 } fdcm_build_timing;
 
 typedef struct fdcm_search_timing {
-    float total_ms;  /* host wall clock of the call */
+    float total_ms;  /* the search's span on the device: kernels + download of the matches */
     float kernel_ms; /* candidate generation + optimisation + compaction on the device */
     int64_t candidates;
     int64_t evaluations; /* translations scored by the reference rule (kept + rejected batches) */

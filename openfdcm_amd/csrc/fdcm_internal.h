@@ -81,7 +81,7 @@ FDCM_HD float lin_spaced_value(int mode, float low, float high, float step, int 
 
 // ---------------------------------------------------------------- handles
 struct Timing {
-    hipEvent_t ev[8] = {};
+    hipEvent_t ev[9] = {};  // 0-5 build stages, 6-7 search kernels, 8 search download
     bool created = false;
 };
 

@@ -531,7 +531,6 @@ int64_t search_capacity(const fdcm_templates* t, int64_t n_scene, int64_t maxT, 
 void run_search(fdcm_featuremap* fm, const fdcm_templates* t, const float* scene, int64_t n_scene, int64_t maxT,
                 int64_t maxS, int optimizer, int64_t batch, int32_t base, fdcm_match* out_device, fdcm_match** out_host,
                 int64_t* n_out) {
-    const auto t0 = std::chrono::steady_clock::now();
     *n_out = 0;
     fm->last_search = fdcm_search_timing{};
     // early-outs of search<DefaultMatch>, defaultmatch.cpp:40-41
@@ -664,13 +663,15 @@ void run_search(fdcm_featuremap* fm, const fdcm_templates* t, const float* scene
         *out_host = result_acquire((size_t)ncand * sizeof(fdcm_match));
         FDCM_HIP(hipMemcpyAsync(*out_host, dst, (size_t)ncand * sizeof(fdcm_match), hipMemcpyDeviceToHost, st));
     }
+    FDCM_HIP(hipEventRecord(ev[8], st));
     FDCM_HIP(hipStreamSynchronize(st));
     finish_build(fm);  // a build queued before this search is complete as well: collect its timings
     *n_out = (int64_t)hc[2];
     fm->last_search.evaluations = (int64_t)hc[0];
     FDCM_HIP(hipEventElapsedTime(&fm->last_search.kernel_ms, ev[6], ev[7]));
-    fm->last_search.total_ms =
-        std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    // the search's own span on the device, kernels and download (host preparation overlaps a build that is
+    // still running, and the wait for that build is not the search's time)
+    FDCM_HIP(hipEventElapsedTime(&fm->last_search.total_ms, ev[6], ev[8]));
 }
 
 }  // namespace fdcm
