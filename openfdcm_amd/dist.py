@@ -110,6 +110,53 @@ def gather_topk(local_topk, k, device, group=None, dst=0):
     return merge_topk([res], k)
 
 
+class FrameGatherer:
+    """Persistent buffers for gathering one frame's match records per call (the per-frame path of the
+    pipeline, where allocations, pageable copies and host-side concatenation would cost more than
+    the frame): one all_gather of the counts (one small sync), one gather of fixed-capacity blocks,
+    a device-side compaction and one pinned download.  Results are views into a ring of `depth` host
+    buffers: a returned array stays valid until `depth` more frames have been gathered."""
+
+    def __init__(self, capacity_records, device, group=None, dst=0, depth=4):
+        self.group, self.dst, self.device = group, dst, device
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.blk = max(1, capacity_records) * RECORD_BYTES
+        cuda = device.type == "cuda"
+        self.count = torch.zeros(1, dtype=torch.int64, device=device)
+        self.counts = torch.zeros(self.world, dtype=torch.int64, device=device)
+        self.counts_host = torch.zeros(self.world, dtype=torch.int64, pin_memory=cuda)
+        if self.rank == dst:
+            self.recv = torch.empty(self.world * self.blk, dtype=torch.uint8, device=device)
+            self.recv_views = list(self.recv.split(self.blk))
+            self.packed = torch.empty(self.world * self.blk, dtype=torch.uint8, device=device)
+            self.host = [torch.empty(self.world * self.blk, dtype=torch.uint8, pin_memory=cuda) for _ in range(depth)]
+            self.turn = 0
+
+    def gather(self, block, n_local):
+        """block: this rank's uint8 buffer of `blk` bytes whose first n_local records are valid."""
+        self.count.fill_(int(n_local))
+        dist.all_gather_into_tensor(self.counts, self.count, group=self.group)
+        self.counts_host.copy_(self.counts, non_blocking=True)
+        dist.gather(block[: self.blk], self.recv_views if self.rank == self.dst else None, dst=self.dst, group=self.group)
+        if self.rank != self.dst:
+            return None
+        if self.device.type == "cuda":
+            torch.cuda.current_stream(self.device).synchronize()  # counts on the host (the gather is queued behind)
+        counts = self.counts_host.tolist()
+        total = sum(counts) * RECORD_BYTES
+        off = 0
+        for r, c in enumerate(counts):  # compaction on the device: 8 slices, one contiguous list
+            nb = c * RECORD_BYTES
+            self.packed[off: off + nb].copy_(self.recv_views[r][:nb], non_blocking=True)
+            off += nb
+        host = self.host[self.turn]
+        self.turn = (self.turn + 1) % len(self.host)
+        host[:total].copy_(self.packed[:total], non_blocking=True)
+        if self.device.type == "cuda":
+            torch.cuda.current_stream(self.device).synchronize()
+        return host[:total].numpy().view(MATCH_DTYPE)
+
+
 class ShardedPipeline:
     """Frame pipeline of one rank plus the in-order gather of every frame's match records to rank 0.
 
@@ -121,10 +168,12 @@ class ShardedPipeline:
     def __init__(self, pipe, world_size, device, capacity_records, slots, group=None, gather=None):
         self.pipe, self.world, self.device, self.slots, self.group = pipe, world_size, device, slots, group
         self.bufs = None
+        self.gatherer = None
         if world_size > 1 if gather is None else gather:
             # one record buffer per slot: ticket t runs on slot t % slots (include/fdcm.h)
             self.bufs = [torch.empty(max(1, capacity_records) * RECORD_BYTES, dtype=torch.uint8, device=device)
                          for _ in range(slots)]
+            self.gatherer = FrameGatherer(capacity_records, device, group=group, depth=slots + 2)
         self.pending = []
         self.submitted = 0
 
@@ -148,12 +197,14 @@ class ShardedPipeline:
         return t
 
     def collect(self):
-        """Wait for the oldest frame; returns its matches on rank 0 (all ranks' shards, rank order)."""
+        """Wait for the oldest frame; returns its matches on rank 0 (all ranks' shards, rank order).
+        With more than one rank the array is a view into a ring of host buffers: it stays valid until
+        slots + 2 more frames have been collected (copy it to keep it longer)."""
         t, buf = self.pending.pop(0)
         res = self.pipe.wait(t)
         if buf is None:
             return res
-        return gather_matches(buf[: int(res) * RECORD_BYTES], self.device, group=self.group)
+        return self.gatherer.gather(buf, int(res))
 
     def close(self):
         while self.pending:

@@ -116,12 +116,13 @@ def _pipe_worker(rank, world, port, out_path):
         cap = 2 * 3 * 3 * len(tmpls) * 9
         sp = ShardedPipeline(_OraclePipe(build, tmpls[b:e], b), world, torch.device("cpu"), cap, slots)
         got = []
+        keep = lambda r: None if r is None else np.array(r, copy=True)  # noqa: E731  (results are views into a ring)
         for sc in scenes:
             if len(sp.pending) == slots:
-                got.append(sp.collect())
+                got.append(keep(sp.collect()))
             sp.submit(np.ascontiguousarray(np.asarray(sc, dtype=np.float32).T))
         while sp.pending:
-            got.append(sp.collect())
+            got.append(keep(sp.collect()))
         sp.close()
         if rank == 0:
             assert len(got) == len(scenes)
