@@ -177,7 +177,7 @@ def main():
 
     # untimed extra: the blocking sequence (one frame in flight) on this rank's shard
     single_frame_ms = None
-    if rank == 0 and args.single_frames > 0:
+    if rank == 0 and world == 1 and args.single_frames > 0:
         fm = DeviceFeatureMap.build(scene, depth=cfg["depth"], coeff=5.0, padding=1.0, distance=cfg["distance"])
         from openfdcm_amd.engine import search_raw
         for _ in range(3):
@@ -232,7 +232,7 @@ def main():
             out["roofline_single_frame"] = {"kernel": STAGE_KERNEL[dom], "achieved": a1, "peak": HBM_PEAK_GBS,
                                             "unit": "GB/s", "frac": a1 / HBM_PEAK_GBS,
                                             "avg_launch_ms": single_stage[dom]}
-        if args.cpu_sample > 0:
+        if args.cpu_sample > 0 and world == 1:  # rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(cfg, scene, all_templates[:per_gpu], min(args.cpu_sample, per_gpu))
     pipe.close()
     if use_dist:
