@@ -37,8 +37,10 @@ extern "C" {
 
 /* core::Distance, modules/core/include/openfdcm/core/imgproc.h:148 */
 enum fdcm_distance { FDCM_L2 = 0, FDCM_L2_SQUARED = 1, FDCM_L1 = 2 };
-/* optimiser strategies: defaultoptimize.cpp:6-93, batchoptimize.cpp:6-123 */
-enum fdcm_optimizer { FDCM_DEFAULT_OPTIMIZE = 0, FDCM_BATCH_OPTIMIZE = 1 };
+/* optimiser strategies: defaultoptimize.cpp:6-93, batchoptimize.cpp:6-123, indulgentoptimize.cpp:6-102.
+ * For FDCM_INDULGENT_OPTIMIZE the batch_size argument of the search calls is the number of passthroughs (it
+ * does not change the result: a passed-through score is re-scored at the same translation). */
+enum fdcm_optimizer { FDCM_DEFAULT_OPTIMIZE = 0, FDCM_BATCH_OPTIMIZE = 1, FDCM_INDULGENT_OPTIMIZE = 2 };
 /* penalty strategies: defaultpenalty.cpp:29-58, exponentialpenalty.cpp:34-64 */
 enum fdcm_penalty { FDCM_DEFAULT_PENALTY = 0, FDCM_EXPONENTIAL_PENALTY = 1 };
 

@@ -142,7 +142,7 @@ class BatchOptimize:
 
 
 class IndulgentOptimize:
-    """Declared for API completeness; not on the accelerated path."""
+    """optimizestrategies/indulgentoptimize.h:30-47; runs on the device like the other two optimisers."""
 
     def __init__(self, indulgent_number_of_passthroughs, pool=None, num_threads=None):
         self._n = int(indulgent_number_of_passthroughs)
@@ -282,8 +282,10 @@ def search(matcher, searcher, optimizer, featuremap, templates, scene):
         kind, batch = _capi.BATCH_OPTIMIZE, optimizer.get_batch_size()
     elif isinstance(optimizer, DefaultOptimize):
         kind, batch = _capi.DEFAULT_OPTIMIZE, 1
+    elif isinstance(optimizer, IndulgentOptimize):
+        kind, batch = _capi.INDULGENT_OPTIMIZE, max(1, optimizer.get_number_of_passthroughs())
     else:
-        raise NotImplementedError("only DefaultOptimize and BatchOptimize run on the GPU path")
+        raise TypeError("optimizer must be DefaultOptimize, BatchOptimize or IndulgentOptimize")
     dt3 = featuremap._dt3 if isinstance(featuremap, FeatureMap) else featuremap
     if not isinstance(dt3, Dt3Cpu):
         raise TypeError("featuremap must be a Dt3Cpu or FeatureMap")

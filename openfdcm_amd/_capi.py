@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libfdcm_hip.so")
 
 FDCM_OK = 0
 L2, L2_SQUARED, L1 = 0, 1, 2
-DEFAULT_OPTIMIZE, BATCH_OPTIMIZE = 0, 1
+DEFAULT_OPTIMIZE, BATCH_OPTIMIZE, INDULGENT_OPTIMIZE = 0, 1, 2
 DEFAULT_PENALTY, EXPONENTIAL_PENALTY = 0, 1
 
 MATCH_DTYPE = np.dtype([("tmpl_idx", "<i4"), ("score", "<f4"), ("transform", "<f4", (6,))])

@@ -302,7 +302,7 @@ static void check_search_args(const fdcm_featuremap* fm, const fdcm_templates* t
     require(fm && t, "null featuremap/templates");
     require(n_scene >= 0 && (n_scene == 0 || scene), "bad scene_lines");
     require(maxT >= 0 && maxS >= 0, "negative search window");
-    require(optimizer == FDCM_DEFAULT_OPTIMIZE || optimizer == FDCM_BATCH_OPTIMIZE, "unknown optimizer");
+    require(optimizer >= FDCM_DEFAULT_OPTIMIZE && optimizer <= FDCM_INDULGENT_OPTIMIZE, "unknown optimizer");
     require(optimizer != FDCM_BATCH_OPTIMIZE || batch >= 1, "batch_size must be >= 1");
     require(fm->device == t->device, "featuremap and templates live on different devices");
 }

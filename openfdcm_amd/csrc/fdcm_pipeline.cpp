@@ -104,7 +104,7 @@ int fdcm_pipeline_create(int64_t depth, float dt3_coeff, float padding, int dist
                          int32_t tmpl_index_base, int n_slots, fdcm_pipeline** out) {
     if (!out || !templates || n_slots < 1 || n_slots > 64 || depth < 0 || distance < FDCM_L2 || distance > FDCM_L1 ||
         max_tmpl_lines < 0 || max_scene_lines < 0 ||
-        (optimizer != FDCM_DEFAULT_OPTIMIZE && optimizer != FDCM_BATCH_OPTIMIZE) ||
+        optimizer < FDCM_DEFAULT_OPTIMIZE || optimizer > FDCM_INDULGENT_OPTIMIZE ||
         (optimizer == FDCM_BATCH_OPTIMIZE && batch_size < 1)) {
         fdcm::set_error("fdcm_pipeline_create: bad argument");
         if (out) *out = nullptr;

@@ -152,6 +152,7 @@ struct OptState {
     float* sc;       // score window (LDS): [0, WIN) positive, [WIN, 2 WIN) negative, [2 WIN] translation 0
     int n_t, lane, B, WIN;
     bool batch_rule;
+    bool reset_back;  // IndulgentOptimize: the negative direction compares against the initial score again
     size_t W, H;
     float tx, ty, savx, savy;
     long long lim_p, lim_n;
@@ -175,8 +176,11 @@ __device__ __forceinline__ void score_range(const float* __restrict__ vol, const
     }
 }
 
-// optimize<BatchOptimize / DefaultOptimize> for one candidate (batchoptimize.cpp:36-98,
-// defaultoptimize.cpp:36-66): speculative scoring in windows, literal replay of the rule.
+// optimize<BatchOptimize / DefaultOptimize / IndulgentOptimize> for one candidate (batchoptimize.cpp:36-98,
+// defaultoptimize.cpp:36-66, indulgentoptimize.cpp:33-77): speculative scoring in windows, literal replay of
+// the rule.  IndulgentOptimize walks like DefaultOptimize (a passed-through score is scored again at the
+// same multiplier until the allowance is used up, then the walk breaks) but starts the negative direction
+// from the initial score again.
 template <bool XF>
 __device__ __forceinline__ void optimise(const float* __restrict__ vol, const OptState& o, float& best, long long& best_k,
                                          unsigned long long& n_eval) {
@@ -203,6 +207,7 @@ __device__ __forceinline__ void optimise(const float* __restrict__ vol, const Op
     best = init;
     float back = init;  // scores.back(): NOT reset between the two directions (batchoptimize.cpp:73)
     for (int dir = 1; dir >= -1; dir -= 2) {
+        if (dir < 0 && o.reset_back) back = init;  // indulgentoptimize.cpp:59-63
         const long long lim = dir > 0 ? o.lim_p : o.lim_n;
         const int off = dir > 0 ? 0 : WIN;
         long long win0 = dir;                       // multiplier held in sc[off]
@@ -431,6 +436,7 @@ __global__ void __launch_bounds__(256) k_search(const SearchParams P) {
         o.L = L; o.sc = sc; o.n_t = n_t; o.W = (size_t)P.W; o.H = (size_t)P.H; o.tx = P.tx; o.ty = P.ty;
         o.savx = savx; o.savy = savy; o.lane = lane;
         o.B = P.optimizer == FDCM_BATCH_OPTIMIZE ? P.batch : 1; o.WIN = P.win; o.batch_rule = P.optimizer == FDCM_BATCH_OPTIMIZE;
+        o.reset_back = P.optimizer == FDCM_INDULGENT_OPTIMIZE;
         // static_cast<long>(max_mul / min_mul), batchoptimize.cpp:51,74
         o.lim_p = (long long)max_mul; o.lim_n = (long long)min_mul;
         optimise<false>(P.vol, o, best, best_k, n_eval);

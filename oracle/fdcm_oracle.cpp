@@ -609,6 +609,38 @@ static inline std::optional<OptimalTranslation> optimizeOne(const Dt3& fm, const
     evaluate(fm, tmpl, {Point2{0, 0}}, sc, n_reads);
     std::vector<Point2> translations{Point2{0, 0}};
     std::vector<float> scores{sc[0]};
+    if (kind == 2) {
+        // optimize<IndulgentOptimize>, indulgentoptimize.cpp:33-77 (batchSize = the number of passthroughs).
+        // A rejected score is "passed through" without advancing the multiplier, so the same translation
+        // is scored again until the allowance is used up: the walk stops at the first rejected score like
+        // DefaultOptimize.  What differs from DefaultOptimize is :59-63: (0,0) and the initial score are
+        // appended again before the negative direction, so it compares against the initial score.
+        const unsigned long allowed = (unsigned long)batchSize;
+        auto walk = [&](int dir) {
+            const long lim = dir > 0 ? static_cast<long>(max_mul) : static_cast<long>(min_mul);
+            unsigned long passthroughs = 0;
+            long tm = dir;
+            while (dir > 0 ? tm <= lim : tm >= lim) {
+                const Point2 tr{(float)tm * sav.x, (float)tm * sav.y};
+                std::vector<float> one;
+                evaluate(fm, tmpl, {tr}, one, n_reads);
+                if (one[0] > scores.back()) {
+                    if (passthroughs >= allowed) break;
+                    ++passthroughs;
+                    continue;
+                }
+                translations.push_back(tr);
+                scores.push_back(one[0]);
+                tm += dir;
+            }
+        };
+        walk(+1);
+        translations.push_back(Point2{0, 0});
+        scores.push_back(sc[0]);
+        walk(-1);
+        size_t best = std::min_element(scores.begin(), scores.end()) - scores.begin();
+        return OptimalTranslation{scores[best], translations[best]};
+    }
     if (kind == 0) batchSize = 1;
     auto run = [&](int dir) {
         const long lim = dir > 0 ? static_cast<long>(max_mul) : static_cast<long>(min_mul);

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libfdcm_oracle.so")
 
 L2, L2_SQUARED, L1 = 0, 1, 2
-DEFAULT_OPTIMIZE, BATCH_OPTIMIZE = 0, 1
+DEFAULT_OPTIMIZE, BATCH_OPTIMIZE, INDULGENT_OPTIMIZE = 0, 1, 2  # for INDULGENT `batch` is the number of passthroughs
 
 
 def build_library(force=False):

@@ -109,7 +109,7 @@ def test_config2_build_bit_exact(amd, name, dist):
 
 
 @pytest.mark.parametrize("kind,batch", [(O.BATCH_OPTIMIZE, 10), (O.BATCH_OPTIMIZE, 3), (O.DEFAULT_OPTIMIZE, 1),
-                                        (O.BATCH_OPTIMIZE, 100)])
+                                        (O.BATCH_OPTIMIZE, 100), (O.INDULGENT_OPTIMIZE, 3)])
 @pytest.mark.parametrize("dist", [O.L2, O.L2_SQUARED, O.L1])
 def test_search_parity_small(amd, kind, batch, dist):
     from openfdcm_amd import synthetic

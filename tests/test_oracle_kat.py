@@ -237,10 +237,10 @@ def test_build_featuremap_lines_are_flat():
         assert abs(feat[p2[1], p2[0]] - feat[p1[1], p1[0]]) <= 1.0
 
 
-# ---------------------------------------------------------------- batchoptimize / defaultoptimize tests
-@pytest.mark.parametrize("kind", [O.BATCH_OPTIMIZE, O.DEFAULT_OPTIMIZE])
+# ---------------------------------------------------------------- batchoptimize / defaultoptimize / indulgentoptimize tests
+@pytest.mark.parametrize("kind", [O.BATCH_OPTIMIZE, O.DEFAULT_OPTIMIZE, O.INDULGENT_OPTIMIZE])
 def test_optimize_known_answers(kind):
-    # batchoptimize.test.cpp:39-116, defaultoptimize.test.cpp (same three cases)
+    # batchoptimize.test.cpp:39-116, defaultoptimize.test.cpp, indulgentoptimize.test.cpp:34-118 (same three cases)
     tmpl = L((10, 0, 10, 10), (0, 0, 10, 0))
     scene = L((15, 0, 15, 10), (5, 0, 15, 0))
     fm = O.build(scene, depth=4, coeff=1.0, padding=1.0)
