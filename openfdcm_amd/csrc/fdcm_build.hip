@@ -81,18 +81,21 @@ struct __attribute__((aligned(16))) ColDesc {
     int next;  // INT_MAX: none
 };
 
-__global__ void __launch_bounds__(256) k_coldesc(const unsigned long long* __restrict__ bitmap,
+// The seed words are cleared as they are read (when one pass reads each word once), so the next build of
+// the same size starts from a zero bitmap without a separate fill.
+__global__ void __launch_bounds__(256) k_coldesc(unsigned long long* __restrict__ bitmap,
                                                  ColDesc* __restrict__ desc, int W, int HW64, long ncols) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long col = (long)blockIdx.x * (blockDim.x >> 6) + wave;  // = k * W + x
     if (col >= ncols) return;
     const long k = col / W, x = col - k * W;
-    const unsigned long long* bw = bitmap + (size_t)col * HW64;
+    unsigned long long* bw = bitmap + (size_t)col * HW64;
     const int ngroups = (HW64 + 63) >> 6;  // groups of 64 words = 4096 rows
     int carry_prev = INT_MIN;              // last seed row in earlier groups
     for (int g = 0; g < ngroups; ++g) {
         const int wi = g * 64 + lane;
         const unsigned long long word = wi < HW64 ? bw[wi] : 0ull;
+        if (ngroups == 1 && word) bw[wi] = 0ull;
         const int last_i = word ? wi * 64 + 63 - __clzll(word) : INT_MIN;
         const int first_i = word ? wi * 64 + (__ffsll((long long)word) - 1) : INT_MAX;
         int carry_next = INT_MAX;  // first seed row in later groups (only when H > 4096)
@@ -820,7 +823,10 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after) {
 
     fm->build_host_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     FDCM_HIP(hipEventRecord(ev[0], st));
-    FDCM_HIP(hipMemsetAsync(fm->bitmap.p, 0, (size_t)ncols * HW64 * 8, st));
+    const long bitmap_words = ncols * HW64;
+    if (!(fm->bitmap_clean && fm->bitmap_words == bitmap_words))
+        FDCM_HIP(hipMemsetAsync(fm->bitmap.p, 0, (size_t)bitmap_words * 8, st));
+    fm->bitmap_clean = false;
     if (fm->n_raster > 0)
         hipLaunchKernelGGL(k_seeds, dim3((unsigned)fm->n_raster), dim3(256), 0, st, d_raster,
                            fm->bitmap.as<unsigned long long>(), W, H, HW64);
@@ -828,6 +834,7 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after) {
     ColDesc* d_desc = fm->coldesc.as<ColDesc>();
     hipLaunchKernelGGL(k_coldesc, dim3((unsigned)((ncols + 3) / 4)), dim3(256), 0, st,
                        fm->bitmap.as<unsigned long long>(), d_desc, W, HW64, ncols);
+    if (HW64 <= 64) { fm->bitmap_clean = true; fm->bitmap_words = bitmap_words; }  // one group of words per column: cleared in place
     FDCM_HIP(hipEventRecord(ev[2], st));
     {
         const unsigned wblocks = (unsigned)((nwaves + 3) / 4);
@@ -880,7 +887,10 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after) {
         const int off_stride = sh_off_stride((int)steps);
         fm->offtab.reserve((size_t)m * off_stride * sizeof(int));
         int* d_off = fm->offtab.as<int>();
-        hipLaunchKernelGGL(k_offsets, dim3((unsigned)((off_stride + 255) / 256), (unsigned)m), dim3(256), 0, st, d_int, d_off, (int)steps, off_stride);
+        if (!(fm->off_m == m && fm->off_steps == steps)) {  // the offsets only depend on the keys (fixed per handle) and the sweep length
+            hipLaunchKernelGGL(k_offsets, dim3((unsigned)((off_stride + 255) / 256), (unsigned)m), dim3(256), 0, st, d_int, d_off, (int)steps, off_stride);
+            fm->off_m = m; fm->off_steps = steps;
+        }
         hipLaunchKernelGGL(k_integral, dim3((unsigned)((chains + 63) / 64), (unsigned)m), dim3(256), 0, st, vol, W, H, d_int, d_off);
     }
     FDCM_HIP(hipEventRecord(ev[5], st));
