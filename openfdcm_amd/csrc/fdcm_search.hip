@@ -589,7 +589,6 @@ void run_search(fdcm_featuremap* fm, const fdcm_templates* t, const float* scene
     fm->s_records.reserve((size_t)ncand * sizeof(fdcm_match));
     fm->s_flags.reserve(2 * ((size_t)ncand + (size_t)nchunks) * sizeof(int));
     fm->s_counter.reserve(64);
-    FDCM_HIP(hipMemsetAsync(fm->s_counter.p, 0, 64, st));
     // keys live at the end of the build plan blob; for adopted volumes they are uploaded there too
     SearchParams P{};
     P.vol = fm->vol.as<float>();
@@ -650,8 +649,11 @@ void run_search(fdcm_featuremap* fm, const fdcm_templates* t, const float* scene
     hipLaunchKernelGGL(k_search, dim3((unsigned)P.nblocks), dim3(256), lds, st, P);
     fdcm_match* dst = out_device;
     if (!dst) {
-        fm->s_out.reserve((size_t)ncand * sizeof(fdcm_match));
+        // host output: one extra record behind the candidates' capacity carries the counters, so that the
+        // matches and their count come back with a single copy
+        fm->s_out.reserve((size_t)(ncand + 1) * sizeof(fdcm_match));
         dst = fm->s_out.as<fdcm_match>();
+        P.counters = reinterpret_cast<unsigned long long*>(dst + ncand);
     }
     int* d_counts = P.flags + ncand;
     int* d_evsums = P.evals + ncand;
@@ -661,17 +663,19 @@ void run_search(fdcm_featuremap* fm, const fdcm_templates* t, const float* scene
     FDCM_HIP(hipEventRecord(ev[7], st));
     FDCM_HIP(hipGetLastError());
     unsigned long long hc[3] = {0, 0, 0};
-    FDCM_HIP(hipMemcpyAsync(hc, fm->s_counter.p, sizeof hc, hipMemcpyDeviceToHost, st));
     if (out_host) {
         // host-output search: the count is not known on the host yet, so the whole candidate capacity
-        // (32 B per candidate) goes to the caller's (pooled, pinned) buffer in the same stream: one
-        // synchronisation per search and no second copy
-        *out_host = result_acquire((size_t)ncand * sizeof(fdcm_match));
-        FDCM_HIP(hipMemcpyAsync(*out_host, dst, (size_t)ncand * sizeof(fdcm_match), hipMemcpyDeviceToHost, st));
+        // (32 B per candidate, plus the counter record) goes to the caller's (pooled, pinned) buffer in the
+        // same stream: one copy, one synchronisation per search
+        *out_host = result_acquire((size_t)(ncand + 1) * sizeof(fdcm_match));
+        FDCM_HIP(hipMemcpyAsync(*out_host, dst, (size_t)(ncand + 1) * sizeof(fdcm_match), hipMemcpyDeviceToHost, st));
+    } else {
+        FDCM_HIP(hipMemcpyAsync(hc, P.counters, sizeof hc, hipMemcpyDeviceToHost, st));
     }
     FDCM_HIP(hipEventRecord(ev[8], st));
     FDCM_HIP(hipStreamSynchronize(st));
     finish_build(fm);  // a build queued before this search is complete as well: collect its timings
+    if (out_host) std::memcpy(hc, *out_host + ncand, sizeof hc);
     *n_out = (int64_t)hc[2];
     fm->last_search.evaluations = (int64_t)hc[0];
     FDCM_HIP(hipEventElapsedTime(&fm->last_search.kernel_ms, ev[6], ev[7]));
