@@ -11,8 +11,8 @@
 //      k_l1_*       L1: forward sweep from descriptors (write V), backward sweep (read V, write V)
 //   K3 k_propagate_reg<M> / k_propagate   orientation propagation, 4m steps per pixel in
 //                   registers (generic depth: LDS) (+ sqrt for L2)                       read V, write V
-//   K4 k_integral_shallow / k_integral_steep   directional prefix sum per slice, one sequential
-//                   float chain per lane (steep slices through LDS tiles)                read V, write V
+//   K4 k_integral   directional prefix sum per slice, one sequential float chain per lane;
+//                   shallow and steep sweeps (the latter through LDS tiles) in one launch  read V, write V
 // Compiled with -ffp-contract=off; divide and sqrt are the correctly rounded forms.
 #include <chrono>
 #include <cstdlib>

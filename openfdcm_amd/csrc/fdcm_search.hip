@@ -273,8 +273,8 @@ __global__ void k_pairs(const SearchParams P) {
 // waves touch unrelated regions and every L2 keeps missing; grouped by scene line, the waves in
 // flight at any time share one or two regions.  Output positions are
 // independent of the processing order (k_chunk_counts / k_scatter compact by candidate position).
-// One workgroup: counting sort by scene line (hashed into kWorkBins) with wave-aggregated LDS
-// atomics; the order inside a group is arbitrary.
+// One workgroup: counting sort by scene line (hashed into kWorkBins) with LDS atomics; the order
+// inside a group is arbitrary.
 static constexpr int kWorkBins = 8192;
 // bin of a pair: its scene line.  (Splitting the two alignments of a pair into separate groups was
 // measured slower: 0.37-0.41 ms against 0.30 ms.)
