@@ -583,7 +583,10 @@ __global__ void __launch_bounds__(256) k_propagate_reg(float* __restrict__ vol, 
 // Chain offsets round(float(i) * r) of every slice (imgproc.h:54-55,70-71), one table row per slice.
 __global__ void k_offsets(const IntegralDesc* __restrict__ desc, int* __restrict__ offtab, int steps, int stride) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
-    if (i < stride) offtab[(size_t)k * stride + i] = i < steps ? (int)roundf((float)i * desc[k].r) : 0;
+    // byte offsets; the padding past the last step holds 2^31 + 4*steps, which stays >= 2^31 after any chain
+    // origin in [-steps, steps) is added: out of range for the buffer unit
+    if (i < stride)
+        offtab[(size_t)k * stride + i] = i < steps ? 4 * (int)roundf((float)i * desc[k].r) : (int)(0x80000000u + 4u * (unsigned)steps);
 }
 
 // Shallow slices (mode 1: the sweep runs along x, the 64 chains of a wave are 64 consecutive y).
@@ -608,15 +611,14 @@ struct ShAddr {
 // col: running pointer to the column of step i0 (advanced by step_elems per step, also past the
 // last step: those descriptors are never dereferenced because their lane offsets are out of range).
 __device__ __forceinline__ void sh_addr(ShAddr& A, float*& col, long step_elems, const int* __restrict__ off, int i0,
-                                        int steps, int H, int c0, int lane4) {
+                                        int H, int c04, int lane4) {
     // 8 dwords with scalar vector loads: the table is padded and its rows are 32-byte aligned
     const int4* op = reinterpret_cast<const int4*>(off + i0);
     const int4 oa = op[0], ob = op[1];
     const int o[kShU] = {oa.x, oa.y, oa.z, oa.w, ob.x, ob.y, ob.z, ob.w};
 #pragma unroll
     for (int j = 0; j < kShU; ++j) {
-        const unsigned ob4 = i0 + j < steps ? (unsigned)(c0 + o[j]) * 4u : 0x80000000u;  // scalar
-        A.voff[j] = (unsigned)lane4 + ob4;  // negative rows wrap to >= 2^31: out of range
+        A.voff[j] = (unsigned)lane4 + (unsigned)(c04 + o[j]);  // negative rows wrap to >= 2^31: out of range
         A.rs[j] = __builtin_amdgcn_make_buffer_rsrc(col, 0, (unsigned)H * 4u, 0x00020000);
         col += step_elems;
     }
@@ -629,7 +631,7 @@ __device__ __forceinline__ void integral_shallow(float* __restrict__ vol, int W,
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int steps = W, span = H;
     const int* off = offtab + (size_t)k * sh_off_stride(steps);
-    const int last_off = off[steps - 1];
+    const int last_off = off[steps - 1] / 4;  // the table holds byte offsets
     const int cmin = -max(0, last_off), cmax = span - 1 - min(0, last_off);
     const int c0 = cmin + ((int)blockIdx.x * 4 + wave) * 64;
     if (c0 > cmax) return;
@@ -642,7 +644,7 @@ __device__ __forceinline__ void integral_shallow(float* __restrict__ vol, int W,
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         ShAddr A;
-        sh_addr(A, col_f, step_elems, off, b * U, steps, H, c0, lane4);
+        sh_addr(A, col_f, step_elems, off, b * U, H, c0 * 4, lane4);
 #pragma unroll
         for (int j = 0; j < U; ++j) v[b][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(A.rs[j], A.voff[j], 0, 0));
     }
@@ -652,13 +654,13 @@ __device__ __forceinline__ void integral_shallow(float* __restrict__ vol, int W,
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             ShAddr A;
-            sh_addr(A, col_c, step_elems, off, i0 + b * U, steps, H, c0, lane4);
+            sh_addr(A, col_c, step_elems, off, i0 + b * U, H, c0 * 4, lane4);
 #pragma unroll
             for (int j = 0; j < U; ++j) {
                 acc = v[b][j] + acc;  // out-of-image loads are +0: 0 + acc == acc exactly (acc >= +0)
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc), A.rs[j], A.voff[j], 0, 0);
             }
-            sh_addr(A, col_f, step_elems, off, i0 + (NB + b) * U, steps, H, c0, lane4);
+            sh_addr(A, col_f, step_elems, off, i0 + (NB + b) * U, H, c0 * 4, lane4);
 #pragma unroll
             for (int j = 0; j < U; ++j) v[b][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(A.rs[j], A.voff[j], 0, 0));
         }
