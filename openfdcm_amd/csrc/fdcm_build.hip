@@ -713,23 +713,24 @@ __device__ __forceinline__ void integral_steep(float* __restrict__ vol, int W, i
         __syncthreads();
         load_tile(t + 2, regs);  // past the last tile every load is out of range
         if (wave == 0) {
-            const int c = c0 + lane;
-            const int my_off = off_at(i0 + (lane & 31));  // lane j < 32 holds the offset of step i0 + j
-            // all 32 reads are issued before the dependent chain of adds (they never alias: one
-            // element per step), so the chain costs 32 adds, not 32 LDS round trips
+            // Lane = chain c0 + lane.  At step ii the chain sits in tile column lane + (off_ii - min off): always
+            // inside the tile.  No validity test is needed here: elements outside the image or past the last
+            // step were loaded as +0 (acc + 0 == acc exactly), every tile element belongs to exactly one chain,
+            // and the write-back below only stores elements of the block's own chains inside the image.
+            const int my_d = off_at(min(i0 + (lane & 31), steps - 1)) - (xb - c0);  // lane j < 32: step i0 + j
+            // all 32 reads are issued before the dependent chain of adds (they never alias: one element per
+            // step), so the chain costs 32 adds, not 32 LDS round trips
             float v[TS];
-            int xi[TS];
+            float* cell[TS];
 #pragma unroll
             for (int ii = 0; ii < TS; ++ii) {
-                const int x = c + __builtin_amdgcn_readlane(my_off, ii);
-                const bool ok = i0 + ii < steps && c <= c_hi && x >= 0 && x < W;
-                xi[ii] = ok ? x - xb : -1;
-                v[ii] = ok ? tile[buf][x - xb][ii] : 0.f;
+                cell[ii] = &tile[buf][lane + __builtin_amdgcn_readlane(my_d, ii)][ii];
+                v[ii] = *cell[ii];
             }
 #pragma unroll
             for (int ii = 0; ii < TS; ++ii) {
-                acc = v[ii] + acc;  // 0 + v == v exactly before the chain starts (v >= +0)
-                if (xi[ii] >= 0) tile[buf][xi[ii]][ii] = acc;
+                acc = v[ii] + acc;
+                *cell[ii] = acc;
             }
         }
         __syncthreads();
