@@ -1,0 +1,62 @@
+/* fdcm_example.c -- the C ABI of libfdcm_hip.so from plain C (C99): the sequence a binding of the
+ * reference would make for one frame, with the host-only tail.  Build:
+ *     gcc -std=c99 -I include examples/fdcm_example.c -o fdcm_example -L openfdcm_amd -lfdcm_hip \
+ *         -Wl,-rpath,$PWD/openfdcm_amd -lm
+ * Without a HIP device the compute calls fail with FDCM_EHIP and the program says so (there is no
+ * CPU fallback); the host-only entry points (filter, penalize, sort) run everywhere. */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "fdcm.h"
+
+int main(void) {
+    /* a 4-line scene and one 3-line template, x1 y1 x2 y2 per line (the reference's LineArray columns) */
+    const float scene[] = {0, 0, 40, 0, 40, 0, 40, 30, 40, 30, 0, 30, 0, 30, 0, 0};
+    const float tmpl[] = {2, 2, 22, 2, 22, 2, 22, 17, 22, 17, 2, 17};
+    const int64_t offsets[] = {0, 3};
+    printf("%s\n", fdcm_version());
+
+    /* host-only: ConcentricRangeStrategy's filter, penalize, sort_matches */
+    int64_t idx[4], n_in = 0;
+    const float center[2] = {20, 15};
+    if (fdcm_filter_in_range(scene, 4, center, 10.f, 18.f, idx, &n_in) != FDCM_OK) return 2;
+    printf("lines with centre in [10, 18) of (20, 15): %lld\n", (long long)n_in);
+    fdcm_match m[3] = {{0, 30.f, {1, 0, 0, 0, 1, 0}}, {0, 10.f, {1, 0, 0, 0, 1, 0}}, {0, 20.f, {1, 0, 0, 0, 1, 0}}};
+    const float len[1] = {55.f};
+    if (fdcm_penalize(FDCM_EXPONENTIAL_PENALTY, 1.5f, m, 3, len, 1) != FDCM_OK) return 2;
+    if (fdcm_sort_matches(m, 3) != FDCM_OK) return 2;
+    printf("best penalised score %.6f (expected %.6f)\n", m[0].score, 10.f / powf(55.f, 1.5f));
+
+    /* device: build + search + device tail */
+    int ndev = 0;
+    fdcm_featuremap* fm = NULL;
+    fdcm_templates* ts = NULL;
+    if (fdcm_device_count(&ndev) != FDCM_OK || ndev == 0 ||
+        fdcm_featuremap_build(scene, 4, 30, 5.f, 2.2f, FDCM_L2, &fm) != FDCM_OK) {
+        printf("no HIP device: %s\n", fdcm_last_error());
+        return 0;
+    }
+    if (fdcm_templates_create(tmpl, offsets, 1, &ts) != FDCM_OK) { printf("%s\n", fdcm_last_error()); return 2; }
+    fdcm_match* out = NULL;
+    int64_t n = 0;
+    if (fdcm_search(fm, ts, scene, 4, 4, 4, FDCM_BATCH_OPTIMIZE, 10, 0, &out, &n) != FDCM_OK) {
+        printf("%s\n", fdcm_last_error());
+        return 2;
+    }
+    fdcm_featuremap_info info;
+    fdcm_featuremap_get_info(fm, &info);
+    printf("feature size %lld x %lld x %lld, %lld raw matches\n", (long long)info.width, (long long)info.height,
+           (long long)info.depth, (long long)n);
+    fdcm_match* best = NULL;
+    int64_t nb = 0;
+    if (fdcm_topk(fm, ts, NULL, 0, 0, FDCM_DEFAULT_PENALTY, 1.f, 3, &best, &nb) == FDCM_OK) {
+        for (int64_t i = 0; i < nb; ++i)
+            printf("  #%lld score %.6f  t = (%.3f, %.3f)\n", (long long)i, best[i].score, best[i].transform[2], best[i].transform[5]);
+        fdcm_matches_free(best);
+    }
+    fdcm_matches_free(out);
+    fdcm_templates_free(ts);
+    fdcm_featuremap_free(fm);
+    return 0;
+}
