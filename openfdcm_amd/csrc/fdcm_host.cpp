@@ -232,6 +232,8 @@ void result_release(fdcm_match* m) {
         std::lock_guard<std::mutex> lk(P.mu);
         auto it = P.capacity.find((void*)m);
         if (it == P.capacity.end()) return;  // not ours: ignore rather than corrupt the heap
+        for (const auto& f : P.free_list)
+            if (f.first == (void*)m) return;  // released twice: ignore
         if (P.free_list.size() < ResultPool::kMaxIdle) {
             P.free_list.emplace_back((void*)m, it->second);
         } else {
