@@ -383,3 +383,18 @@ def test_device_topk_equals_penalize_sort_slice(amd, penalty, tau):
     got = topk(fm, tset, 25, penalty, tau, tmpl_index_base=7, device_ptr=buf.data_ptr(), n=n)
     assert got.tobytes() == host_tail(25).tobytes()
     assert len(topk(fm, tset, 0, penalty, tau, tmpl_index_base=7)) == 0
+
+
+def test_search_many_templates_generic_work_list(amd):
+    """More than 16384 pair slots: the work list is built by the generic (memory-resident) path."""
+    from openfdcm_amd import synthetic, _capi
+    from openfdcm_amd.engine import DeviceFeatureMap, DeviceTemplates, search_raw
+    S = 200
+    scene = synthetic.scene(S, 45, 41)
+    tmpls = synthetic.templates(1500, 6, S, 42) + [np.zeros((4, 0), np.float32)] + synthetic.templates(30, 2, S, 43)
+    dev = DeviceFeatureMap.build(scene, depth=20, coeff=5.0, padding=1.0, distance=O.L2)
+    orc = O.build(scene, depth=20, coeff=5.0, padding=1.0, distance=O.L2, nthreads=8)
+    got = search_raw(dev, DeviceTemplates(tmpls), scene, 4, 3, _capi.BATCH_OPTIMIZE, 10)
+    want = O.search(orc, tmpls, scene, 4, 3, kind=O.BATCH_OPTIMIZE, batch=10, nthreads=8)
+    assert len(tmpls) * 4 * 3 > 16384 and len(want) > 20000
+    assert assert_matches_close(got, want, "1531 templates"), "not bit-identical"
