@@ -338,21 +338,41 @@ __global__ void __launch_bounds__(1024) k_worklist(const SearchParams P, long lo
         return;
     }
     __syncthreads();
-    const long long rounds = (n_slots + 1023) / 1024;
-    for (long long r = 0; r < rounds; ++r) {
-        const long long i = r * 1024 + tid;
-        const int2 pr = i < n_slots ? P.pairs[i] : make_int2(-1, -1);
-        const int rank = work_rank(bins, work_key(pr.y), pr.x >= 0, lane);
-        if (pr.x >= 0) slot_rank[i] = rank;
+    // 16 slots per thread at a time, all loads of a batch in flight together
+    constexpr int RB = 16;
+    for (long long b0 = 0; b0 < n_slots; b0 += (long long)RB * 1024) {
+        int2 pr[RB];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            const long long i = b0 + (long long)r * 1024 + tid;
+            pr[r] = i < n_slots ? P.pairs[i] : make_int2(-1, -1);
+        }
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            const long long i = b0 + (long long)r * 1024 + tid;
+            const int rank = work_rank(bins, work_key(pr[r].y), pr[r].x >= 0, lane);
+            if (pr[r].x >= 0) slot_rank[i] = rank;
+        }
     }
     __syncthreads();
     work_scan(bins, partial, tid);
     __syncthreads();
-    for (long long i = tid; i < n_slots; i += 1024) {  // scatter
-        const int2 pr = P.pairs[i];
-        if (pr.x < 0) continue;
-        const int t = (int)(i / P.pairs_stride);
-        work[bins[work_key(pr.y)] + slot_rank[i]] = make_int2(t, (int)(i - (long long)t * P.pairs_stride));
+    for (long long b0 = 0; b0 < n_slots; b0 += (long long)RB * 1024) {  // scatter
+        int2 pr[RB];
+        int rk[RB];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            const long long i = b0 + (long long)r * 1024 + tid;
+            pr[r] = i < n_slots ? P.pairs[i] : make_int2(-1, -1);
+            rk[r] = i < n_slots ? slot_rank[i] : 0;
+        }
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            if (pr[r].x < 0) continue;
+            const long long i = b0 + (long long)r * 1024 + tid;
+            const int t = (int)(i / P.pairs_stride);
+            work[bins[work_key(pr[r].y)] + rk[r]] = make_int2(t, (int)(i - (long long)t * P.pairs_stride));
+        }
     }
 }
 
