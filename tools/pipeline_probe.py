@@ -4,7 +4,6 @@ rebuild -> search step; checks that every frame returns the blocking call's matc
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import numpy as np
 from openfdcm_amd import synthetic, _capi
 from openfdcm_amd.engine import DeviceFeatureMap, DeviceTemplates, FramePipeline, search_raw
 

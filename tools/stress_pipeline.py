@@ -1,4 +1,4 @@
-import os, sys, time
+import os, sys
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 sys.path.insert(0, "/root/repo")
 import numpy as np
