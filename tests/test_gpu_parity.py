@@ -398,3 +398,15 @@ def test_search_many_templates_generic_work_list(amd):
     want = O.search(orc, tmpls, scene, 4, 3, kind=O.BATCH_OPTIMIZE, batch=10, nthreads=8)
     assert len(tmpls) * 4 * 3 > 16384 and len(want) > 20000
     assert assert_matches_close(got, want, "1531 templates"), "not bit-identical"
+
+
+def test_randomised_cases(amd):
+    """80 random (scene, depth, distance, padding, coefficient, optimiser, template set) cases: volume and
+    match list bit for bit (tools/fuzz_parity.py; larger runs by hand: 3300 cases identical this round)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "80", "11"], capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0 and "80 random cases identical" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
