@@ -963,5 +963,31 @@ void fdcmo_evaluate(void* h, const float* tmpl, long n, const float* tr, long nt
     std::memcpy(scores, s.data(), s.size() * 4);
 }
 float fdcmo_eigen_sum(const float* v, long n) { return eigenSum(v, n); }
+// unit-level entry points for the math.test.cpp known answers
+void fdcmo_argsort_greater(const float* v, long n, long* out) {
+    auto ind = argsortGreater(std::vector<float>(v, v + n));
+    std::memcpy(out, ind.data(), ind.size() * sizeof(long));
+}
+long fdcmo_binary_search_greater(const float* sorted_desc, long n, float value) {
+    return (long)binarySearchGreater(std::vector<float>(sorted_desc, sorted_desc + n), value);
+}
+void fdcmo_minmax_point(const float* lines, long n, float* out4) {
+    Point2 mn, mx;
+    minmaxPoint(fromRaw(lines, n), mn, mx);
+    out4[0] = mn.x; out4[1] = mn.y; out4[2] = mx.x; out4[3] = mx.y;
+}
+void fdcmo_line_props(const float* line, float* out4) {  // angle, length, normalised direction
+    out4[0] = getAngle(line); out4[1] = getLength(line);
+    Point2 d = normalize(line); out4[2] = d.x; out4[3] = d.y;
+}
+void fdcmo_translate(const float* lines, long n, float tx, float ty, float* out) {
+    Lines r = translate(fromRaw(lines, n), {tx, ty});
+    std::memcpy(out, r.d.data(), r.d.size() * 4);
+}
+void fdcmo_combine(float tx, float ty, const float* T, float* out6) {
+    Mat23 m; std::memcpy(m.m, T, 24);
+    Mat23 c = combine({tx, ty}, m);
+    std::memcpy(out6, c.m, 24);
+}
 float fdcmo_atanf(float x) { return std::atan(x); }
 }

@@ -336,3 +336,52 @@ def evaluate(fm, tmpl, translations):
 def eigen_sum(v):
     v = np.ascontiguousarray(v, dtype=np.float32)
     return float(lib().fdcmo_eigen_sum(_fp(v), v.size))
+
+
+# ---- unit-level entry points for the math.test.cpp known answers
+def argsort_greater(v):
+    v = np.ascontiguousarray(v, dtype=np.float32)
+    out = np.zeros(v.size, dtype=np.int64)
+    lib().fdcmo_argsort_greater(_fp(v), v.size, _lp(out))
+    return out.tolist()
+
+
+def binary_search_greater(sorted_desc, value):
+    v = np.ascontiguousarray(sorted_desc, dtype=np.float32)
+    f = lib().fdcmo_binary_search_greater
+    f.restype = C.c_long
+    f.argtypes = [C.POINTER(C.c_float), C.c_long, C.c_float]
+    return int(f(_fp(v), v.size, float(value)))
+
+
+def minmax_point(lines):
+    s = as_lines(lines)
+    out = np.zeros(4, dtype=np.float32)
+    lib().fdcmo_minmax_point(_fp(s), s.shape[0], _fp(out))
+    return out[:2].copy(), out[2:].copy()
+
+
+def line_props(line):
+    """(angle, length, normalised direction) of one line x1, y1, x2, y2."""
+    l = np.ascontiguousarray(line, dtype=np.float32)
+    out = np.zeros(4, dtype=np.float32)
+    lib().fdcmo_line_props(_fp(l), _fp(out))
+    return float(out[0]), float(out[1]), out[2:].copy()
+
+
+def translate(lines, t):
+    s = as_lines(lines)
+    out = np.zeros_like(s)
+    f = lib().fdcmo_translate
+    f.argtypes = [C.POINTER(C.c_float), C.c_long, C.c_float, C.c_float, C.POINTER(C.c_float)]
+    f(_fp(s), s.shape[0], float(t[0]), float(t[1]), _fp(out))
+    return from_lines(out)
+
+
+def combine(translation, T):
+    t = np.ascontiguousarray(T, dtype=np.float32).reshape(6)
+    out = np.zeros(6, dtype=np.float32)
+    f = lib().fdcmo_combine
+    f.argtypes = [C.c_float, C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    f(float(translation[0]), float(translation[1]), _fp(t), _fp(out))
+    return out.reshape(2, 3)

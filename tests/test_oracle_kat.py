@@ -316,3 +316,34 @@ def test_concentric_range_known_answers():
     inf = float("inf")
     for lo, hi, want in [(0, 2, (0, 1)), (3, 15, (0, 3)), (3, inf, (0, 3)), (2, 4, (0, 0))]:
         assert tuple(O.concentric_search(one, scene, 1, 1, (4, 0), lo, hi)[0]) == want
+
+
+# ---------------------------------------------------------------- math.test.cpp (vectors, lines)
+def test_argsort_binary_search_minmax_point():
+    # math.test.cpp:33-63
+    assert O.argsort_greater([-4, 3, -1, 2]) == [1, 3, 2, 0]
+    # binarySearch returns the index of the closest element; the reference's case is ascending with the
+    # default comparator, the path uses the descending variant (defaultsearch.cpp:41): negate both
+    vec = [0, 2, 3, 6, 7, 10, 14, 30, 40, 123]
+    desc = [-x for x in vec]
+    for value, idx in [(0, 0), (123, 9), (2, 1), (40, 8), (5, 3), (4, 2)]:
+        assert O.binary_search_greater(desc, -value) == idx, (value, idx)
+    mn, mx = O.minmax_point(L((0, -4, 0, 0), (0, 0, 2, 0), (0, 0, 8, 8), (0, 0, 0, 16)))
+    assert np.allclose(mn, [0, -4], atol=1e-5) and np.allclose(mx, [8, 16], atol=1e-5)
+
+
+def test_line_angle_length_normalize_translate():
+    # math.test.cpp:82-129,195-211 with the fixture at :84-89
+    lines = [(0, 0, 2, 2), (0, 0, 1, 0), (-1, 1, 0, 0)]
+    exp_angle = [np.pi / 4, 0.0, -np.pi / 4]
+    exp_len = [np.sqrt(8.0), 1.0, np.sqrt(2.0)]
+    exp_dir = [(np.sqrt(2) / 2, np.sqrt(2) / 2), (1.0, 0.0), (np.sqrt(2) / 2, -np.sqrt(2) / 2)]
+    for l, a, ln, d in zip(lines, exp_angle, exp_len, exp_dir):
+        angle, length, direction = O.line_props(l)
+        assert abs(angle - a) < 1e-5 and abs(length - ln) < 1e-5 and np.allclose(direction, d, atol=1e-5)
+    # getTemplateLengths == getLength(tmpl).sum()
+    assert abs(O.eigen_sum(np.array(exp_len, dtype=np.float32)) - float(np.float32(sum(np.float32(x) for x in exp_len)))) < 1e-5
+    moved = O.translate(L((0, 0, 1, 1), (1, 1, 2, 2)), (1, 2))
+    assert np.allclose(moved, L((1, 2, 2, 3), (2, 3, 3, 4)), atol=1e-6)
+    # combine(translation, transform), the overload defaultmatch.cpp:83 uses (math.h:427-432)
+    assert np.allclose(O.combine((3, 4), [[-1, 0, 1], [0, -1, 2]]), [[-1, 0, 4], [0, -1, 6]], atol=1e-6)
