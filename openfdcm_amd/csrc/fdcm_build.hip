@@ -442,15 +442,16 @@ __global__ void __launch_bounds__(256) k_pass2_l2(const ColDesc* __restrict__ de
 __global__ void __launch_bounds__(256) k_l1_forward(const ColDesc* __restrict__ desc, float* __restrict__ vol, int W,
                                                     int H, int HW64, long nwaves) {
     const int tid = threadIdx.x, lane = tid & 63;
-    const long wid = (long)blockIdx.x * 4 + (tid >> 6);
+    const long wid = (long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(tid >> 6);
     if (wid >= nwaves) return;
     const long k = wid / HW64;
     const int c = (int)(wid - k * HW64);
     const int y = c * 64 + lane;
     const bool active = y < H;
     const ColDesc* dp = desc + ((size_t)k * HW64 + c) * W;
-    float* row = vol + (size_t)k * W * H + (active ? y : 0);
-    const size_t H_ = (size_t)H;
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc(vol + (size_t)k * W * H, 0, (unsigned)((size_t)W * H * 4), 0x00020000);
+    const unsigned vrow = active ? (unsigned)y * 4u : 0x80000000u;  // rows past the image: dropped stores
+    const int colB = H * 4;
     float run = 0.f;
     ColDesc dcur = dp[min(lane, W - 1)];
     for (int q0 = 0; q0 < W; q0 += 64) {
@@ -462,42 +463,52 @@ __global__ void __launch_bounds__(256) k_l1_forward(const ColDesc* __restrict__ 
             desc_lane(dcur, j, wc, pc, nc);
             const float cq = column_value<false>(wc, pc, nc, lane, y);
             run = (q0 + j == 0) ? cq : std_min(cq, run + 1);
-            if (active) row[(size_t)(q0 + j) * H_] = run;
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(run), rs, vrow, (q0 + j) * colB, 0);
         }
         dcur = dnext;
     }
 }
 
 __global__ void __launch_bounds__(256) k_l1_backward(float* __restrict__ vol, int W, int H, long nrows) {
-    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= nrows) return;
-    const long k = gid / H, y = gid - k * H;
-    float* row = vol + (size_t)k * W * H + y;
-    const size_t H_ = (size_t)H;
+    // one wave = 64 consecutive rows of one slice (H is padded per slice so that waves never straddle slices)
+    const int lane = threadIdx.x & 63;
+    const long wid = (long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wps = (H + 63) >> 6;  // waves per slice
+    const long k = wid / wps;
+    const int y = (int)(wid - k * wps) * 64 + lane;
+    if (k * (long)H >= nrows) return;  // wave-uniform
+    // The slice through a buffer descriptor: the column is the scalar offset, the row the lane offset; rows past
+    // the image and columns before 0 get a lane offset of 2^31 (loads 0, drops stores), so no memory operation
+    // sits behind a branch and two batches of loads stay in flight behind the stores.
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc(vol + (size_t)k * W * H, 0, (unsigned)((size_t)W * H * 4), 0x00020000);
+    const unsigned vrow = y < H ? (unsigned)y * 4u : 0x80000000u;
+    const int colB = H * 4;
     constexpr int U = 16;
     float va[U], vb[U];
     // q runs W-2 .. 0; chunk t covers q = W-2-t*U-j.  Loads never alias earlier stores of the sweep.
-    auto fetch = [&](int t, float* v) {
+    auto fetch = [&](int t, float (&v)[U]) {
 #pragma unroll
         for (int j = 0; j < U; ++j) {
-            const int q = W - 2 - t * U - j;
-            v[j] = q >= 0 ? row[(size_t)q * H_] : 0.f;
+            const int q = W - 2 - t * U - j;  // uniform
+            v[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, q >= 0 ? vrow : 0x80000000u, max(q, 0) * colB, 0));
         }
     };
-    float run = row[(size_t)(W - 1) * H_];
-    fetch(0, va);
-    for (int t = 0; t * U < W - 1; ++t) {
-        fetch(t + 1, vb);
+    auto consume = [&](int t, const float (&v)[U], float& run) {
 #pragma unroll
         for (int j = 0; j < U; ++j) {
             const int q = W - 2 - t * U - j;
-            if (q >= 0) {
-                run = std_min(va[j], run + 1);
-                row[(size_t)q * H_] = run;
-            }
+            run = std_min(v[j], run + 1);  // past column 0 the value is unused and the store is dropped
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(run), rs, q >= 0 ? vrow : 0x80000000u, max(q, 0) * colB, 0);
         }
-#pragma unroll
-        for (int j = 0; j < U; ++j) va[j] = vb[j];
+    };
+    float run = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, vrow, (W - 1) * colB, 0));
+    fetch(0, va);
+    fetch(1, vb);
+    for (int t = 0; t * U < W - 1; t += 2) {
+        consume(t, va, run);
+        fetch(t + 2, va);
+        consume(t + 1, vb, run);  // past column 0: dropped stores
+        fetch(t + 3, vb);
     }
 }
 
@@ -843,7 +854,10 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after) {
         const unsigned wblocks = (unsigned)((nwaves + 3) / 4);
         if (fm->distance == FDCM_L1) {
             hipLaunchKernelGGL(k_l1_forward, dim3(wblocks), dim3(256), 0, st, d_desc, vol, W, H, HW64, nwaves);
-            hipLaunchKernelGGL(k_l1_backward, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, st, vol, W, H, nrows);
+            {
+                const long bwaves = (long)m * ((H + 63) / 64);  // 64 rows of one slice per wave
+                hipLaunchKernelGGL(k_l1_backward, dim3((unsigned)((bwaves + 3) / 4)), dim3(256), 0, st, vol, W, H, nrows);
+            }
         } else {
             const size_t NT = (size_t)nwaves * R;
             int* sv = fm->stack.as<int>();
