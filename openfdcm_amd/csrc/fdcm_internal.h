@@ -97,7 +97,6 @@ struct fdcm_featuremap {
     bool bitmap_clean = false;   // k_coldesc left the seed bitmap zeroed (it clears what it reads)
     long bitmap_words = 0;       // size the bitmap had then
     int off_m = 0, off_steps = 0;  // the chain-offset table in `offtab` is valid for this depth and sweep length
-    bool throughput = false;     // a pipeline slot: other frames share the GPU, prefer the variants with more waves per SIMD
     bool build_pending = false;  // the last build is queued on `stream` but has not been waited for
     float build_host_ms = 0.f;   // host time of that call up to its first kernel launch
     // geometry

@@ -62,7 +62,6 @@ void run_frame(fdcm_pipeline* p, Slot& s) {
     int rc = s.fm ? fdcm_featuremap_rebuild(s.fm, s.scene.data(), s.n_lines)
                   : fdcm_featuremap_build(s.scene.data(), s.n_lines, p->depth, p->coeff, p->padding, p->distance, &s.fm);
     if (rc == FDCM_OK) {
-        s.fm->throughput = p->slots.size() > 1;
         rc = s.out_device
                  ? fdcm_search_device(s.fm, p->templates, s.scene.data(), s.n_lines, p->maxT, p->maxS, p->optimizer,
                                       p->batch, p->base, s.out_device, &s.n_out)

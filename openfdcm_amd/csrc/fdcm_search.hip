@@ -376,14 +376,9 @@ __global__ void __launch_bounds__(1024) k_worklist(const SearchParams P, long lo
     }
 }
 
-// SW: the wave index is taken as a scalar (readfirstlane), which lets the compiler keep the candidate's
-// uniform values and addresses in SGPRs: faster alone (0.26 -> 0.21 ms) but 141 instead of 111 VGPRs, i.e. 3
-// instead of 4 waves per SIMD, which costs throughput when several frames share the GPU.  Pipeline slots
-// use the SW = false variant.
-template <bool SW>
 __global__ void __launch_bounds__(256) k_search(const SearchParams P) {
     extern __shared__ float lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = SW ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int t, local;
     if (P.work) {
         // List order = launch order: workgroups go round-robin to the XCDs, so all XCDs work on the same
@@ -653,10 +648,7 @@ void run_search(fdcm_featuremap* fm, const fdcm_templates* t, const float* scene
     const size_t lds = lds_floats * sizeof(float);
     if (lds > 160 * 1024) throw std::string("scene/template too large for the search kernel's LDS staging");
     if (lds > 64 * 1024)
-    {
-        FDCM_HIP(hipFuncSetAttribute((const void*)k_search<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        FDCM_HIP(hipFuncSetAttribute((const void*)k_search<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    }
+        FDCM_HIP(hipFuncSetAttribute((const void*)k_search, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t* ev = fm->timing.ev;
     FDCM_HIP(hipEventRecord(ev[6], st));
     hipLaunchKernelGGL(k_pairs, dim3((unsigned)(((size_t)t->T * maxT + 255) / 256)), dim3(256), 0, st, P);
@@ -674,8 +666,7 @@ void run_search(fdcm_featuremap* fm, const fdcm_templates* t, const float* scene
         P.work = nullptr;
         P.nblocks = (int)((size_t)t->T * P.bpt);
     }
-    if (fm->throughput) hipLaunchKernelGGL(k_search<false>, dim3((unsigned)P.nblocks), dim3(256), lds, st, P);
-    else hipLaunchKernelGGL(k_search<true>, dim3((unsigned)P.nblocks), dim3(256), lds, st, P);
+    hipLaunchKernelGGL(k_search, dim3((unsigned)P.nblocks), dim3(256), lds, st, P);
     fdcm_match* dst = out_device;
     if (!dst) {
         // host output: one extra record behind the candidates' capacity carries the counters, so that the
