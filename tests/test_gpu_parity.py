@@ -410,3 +410,22 @@ def test_randomised_cases(amd):
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "80", "11"], capture_output=True,
                          text=True, timeout=600)
     assert out.returncode == 0 and "80 random cases identical" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_frame_pipeline_reports_a_failed_frame_and_keeps_going(amd):
+    """A frame whose build fails (feature size above the supported maximum) is reported by its wait();
+    the slot stays usable."""
+    from openfdcm_amd import synthetic, _capi
+    from openfdcm_amd.engine import DeviceTemplates, FramePipeline
+    S = 128
+    good = synthetic.scene(S, 20, 77)
+    huge = np.array([[0.0, 0.0], [0.0, 0.0], [40000.0, 0.0], [0.0, 40000.0]], dtype=np.float32)  # 40001 x 40001
+    tset = DeviceTemplates(synthetic.templates(5, 8, S, 78))
+    pipe = FramePipeline(tset, depth=8, coeff=5.0, padding=1.0, distance=O.L2, slots=2)
+    t0, t1, = pipe.submit(good), pipe.submit(huge)
+    first = np.array(pipe.wait(t0), copy=True)
+    with pytest.raises(_capi.FdcmError, match="feature size"):
+        pipe.wait(t1)
+    t2, t3 = pipe.submit(good), pipe.submit(good)  # t3 runs on the slot whose last frame failed
+    assert pipe.wait(t2).tobytes() == first.tobytes() and pipe.wait(t3).tobytes() == first.tobytes()
+    pipe.close()
