@@ -870,8 +870,13 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after) {
 #define FDCM_K2(RR, CC, SS, PP) hipLaunchKernelGGL((k_pass2_l2<RR, CC, SS, PP>), dim3(wblocks), dim3(256), 0, st, d_desc, vol, W, H, HW64, nwaves, sv, sf, sz)
             static const bool no_pf = getenv("FDCM_K2_SERIAL_FILL") != nullptr;  // tuning override
             if (R == 64) { if (small_grid) FDCM_K2(64, 16, 8, false); else FDCM_K2(64, 8, 4, false); }
-            else if (R == 32) { if (small_grid && !no_pf) FDCM_K2(32, 32, 8, true); else if (small_grid) FDCM_K2(32, 32, 16, false); else FDCM_K2(32, 16, 8, false); }
-            else { if (small_grid && !no_pf) FDCM_K2(16, 64, 4, true); else if (small_grid) FDCM_K2(16, 64, 16, false); else FDCM_K2(16, 32, 8, false); }
+            else if (R == 32) {
+                if (small_grid && !no_pf) FDCM_K2(32, 32, 8, true); else if (small_grid) FDCM_K2(32, 32, 16, false);
+                else if (!no_pf) FDCM_K2(32, 16, 4, true); else FDCM_K2(32, 16, 8, false);
+            } else {
+                if (small_grid && !no_pf) FDCM_K2(16, 64, 4, true); else if (small_grid) FDCM_K2(16, 64, 16, false);
+                else if (!no_pf) FDCM_K2(16, 32, 4, true); else FDCM_K2(16, 32, 8, false);
+            }
 #undef FDCM_K2
         }
     }
