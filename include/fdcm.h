@@ -120,7 +120,11 @@ int fdcm_templates_lengths(const fdcm_templates* t, float* lengths /* n_template
  *      DefaultOptimize / BatchOptimize(batch_size): defaultmatch.cpp:32-89 ----
  * Returns the matches in the reference's positional order (template order x search-combination
  * order x 2 alignments, candidates without a value skipped).  tmpl_idx is offset by
- * tmpl_index_base (0 for a single GPU; the shard's first template for sharded runs). */
+ * tmpl_index_base (0 for a single GPU; the shard's first template for sharded runs).
+ * The limits behave as the reference's min(): max_tmpl_lines above a template's line count means all of its
+ * lines (defaultsearch.cpp:38, size_t), max_scene_lines above n_scene_lines means every scene line
+ * (defaultsearch.h:42-46; the reference's int casts make values >= 2^31 undefined there, here they also mean
+ * "every line"). */
 int fdcm_search(const fdcm_featuremap* fm, const fdcm_templates* templates, const float* scene_lines,
                 int64_t n_scene_lines, int64_t max_tmpl_lines, int64_t max_scene_lines, int optimizer,
                 int64_t batch_size, int32_t tmpl_index_base, fdcm_match** out, int64_t* n_out);

@@ -165,7 +165,8 @@ __device__ __forceinline__ void desc_lane(const ColDesc& d, int j, unsigned long
 template <int R, int C, int SG, bool PF>
 __global__ void __launch_bounds__(256) k_pass2_l2(const ColDesc* __restrict__ desc, float* __restrict__ vol, int W,
                                                   int H, int HW64, long nwaves, int* __restrict__ sv,
-                                                  float* __restrict__ sf, float* __restrict__ sz) {
+                                                  float* __restrict__ sf, float* __restrict__ sz,
+                                                  const int* __restrict__ only_flagged) {
     constexpr int NR = 4 * R;    // distinct rows per block
     __shared__ int r_v[C][NR];
     __shared__ float r_f[C][NR];
@@ -180,6 +181,8 @@ __global__ void __launch_bounds__(256) k_pass2_l2(const ColDesc* __restrict__ de
     if (wid >= nwaves) return;  // wave-uniform
     constexpr int SUB = 64 / R;  // waves per 64-row chunk
     const long chunk = wid / SUB;
+    // redo mode (after the segmented kernels below): only the chunks they flagged
+    if (only_flagged && __builtin_amdgcn_readfirstlane(only_flagged[chunk]) == 0) return;
     const int sub = (int)(wid - chunk * SUB);
     const long k = chunk / HW64;
     const int c = (int)(chunk - k * HW64);
@@ -433,6 +436,365 @@ __global__ void __launch_bounds__(256) k_pass2_l2(const ColDesc* __restrict__ de
         }
         const float dq = (float)(q - cv);  // dq * dq rounds like the reference's float(long(dq * dq))
         if (mine && y < H && (PF || lane < R)) row[(size_t)q * H_] = base_val + dq * dq;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ K2, segmented
+// The same literal pass (imgproc.h:91-130), with the sequential chain of a row cut into S segments that run
+// in different waves, and the fill split from the construction.
+//
+// Why a row can be cut.  Once a column c has been pushed it stays on the stack as long as no later column
+// pops it, and while it stays, the algorithm never looks at the entries below it: every test of a later column
+// q is against the top entry and its z, and the only test that involves what lies below c is q against c
+// itself, s(q, c) > z_c with z_c = s(c, entry below c).  So the columns after c can be run on a stack whose
+// bottom is c with z = -inf ("local run"): every test not against the bottom is the real test on the same
+// operands, and a test against the bottom always pushes.  The local run equals the real one exactly when the
+// real tests against c all push as well, i.e. when min over those tests of s(q, c) > z_c -- one float per
+// segment (minF), compared afterwards with the real z_c, which is the z of the previous segment's top entry
+// (c is the last column of the previous segment, hence its top).  If the comparison fails for a row, its chunk
+// is flagged and redone by the one-wave-per-chunk kernel above; nothing is assumed about floating point.
+//
+// Which column.  The speculation holds when c is a vertex of the final envelope.  The owner of a pixel x
+// (the column minimising f_u + (x - u)^2) is one, so phase A of k_env finds, per row, the owner of the
+// junction pixel x_j by scanning the seeded columns outwards from x_j until the distance alone exceeds the
+// best value; x_j is the same for all rows of a slice (the j/S quantile of its seeded columns).
+//
+//   k_env     block = one 64-row chunk, wave w = segment w: seeded mask of the slice, junction owners
+//             (phase A), local literal run over the columns (c_w, c_{w+1}] (phase B); stack = top entry in
+//             registers + a C-entry LDS ring + HBM scratch; writes each local stack and minF
+//   k_addend  lane = row: checks the junctions, walks the concatenated stack once and writes the list of
+//             entries that own pixels as (first pixel, column, addend); the addend is f[v] when the entry
+//             takes over at or before its own column, else the already written g[v] (the in-place quirk,
+//             imgproc.h:126-127), re-evaluated from the owner of pixel v found a few entries back
+//   k_fill    lane = (row, quarter of the pixels): pure fill from the owner list, entries staged through
+//             LDS in rounds of RE
+static constexpr int kSegMax = 4;
+static constexpr int kFillParts = 4;
+
+struct K2Buf {
+    int* ev; float* ef; float* ez;        // envelope entries [slot][row]
+    unsigned* lpk; float* lb;             // owner list [index][row]: (first pixel << 16 | column), addend
+    int* tcnt; float* tminf; int* tslot;  // per (segment, row): entries, min s against the bottom, first slot
+    int* lcount;                          // owner entries per row
+    int* partidx;                         // [part - 1][row]: list index that owns the first pixel of fill part 1..3
+    int* flags;                           // per 64-row chunk: 1 = redo with k_pass2_l2
+    long NR;                              // rows of the scratch arrays (chunks * 64)
+};
+
+__device__ __forceinline__ unsigned long long uni64(unsigned long long v) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ void desc_lane4(const uint4& d, int j, unsigned long long& wc, int& pc, int& nc) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)d.x, j);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)d.y, j);
+    wc = ((unsigned long long)hi << 32) | lo;
+    pc = __builtin_amdgcn_readlane((int)d.z, j);
+    nc = __builtin_amdgcn_readlane((int)d.w, j);
+}
+
+template <int C>
+__global__ void __launch_bounds__(256) k_env(const ColDesc* __restrict__ desc, int W, int H, int HW64, int S, K2Buf B) {
+    __shared__ unsigned long long smask[256];  // seeded columns of the slice, 64 per word (W <= 16384)
+    __shared__ int cj[kSegMax + 1][64];        // junction column of segment w per row
+    __shared__ int r_v[C][256];
+    __shared__ float r_f[C][256];
+    __shared__ float r_z[C][256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long chunk = blockIdx.x;
+    const long k = chunk / HW64;
+    const int c = (int)(chunk - k * HW64);
+    const int y = c * 64 + lane;
+    const size_t NR = (size_t)B.NR;
+    const size_t r = (size_t)chunk * 64 + lane;
+    const uint4* dp = reinterpret_cast<const uint4*>(desc + ((size_t)k * HW64 + c) * W);
+    const int nwords = (W + 63) >> 6;
+    const float inf = f_inf();
+    if (tid == 0) B.flags[chunk] = 0;
+    for (int b = wave; b < nwords; b += S) {
+        const int x = b * 64 + lane;
+        const uint4 d = dp[min(x, W - 1)];
+        const bool seeded = x < W && !((d.x | d.y) == 0u && (int)d.z == INT_MIN && (int)d.w == INT_MAX);
+        const unsigned long long mk = __ballot(seeded);
+        if (lane == 0) smask[b] = mk;
+    }
+    __syncthreads();
+    // ---- phase A: the owner of the junction pixel of this wave's segment start
+    if (wave > 0) {
+        int n = 0;
+        for (int b = 0; b < nwords; ++b) n += __popcll(uni64(smask[b]));
+        int x = (int)(((long)W * wave) / S);
+        if (n >= 2 * S) {
+            int t = (int)(((long)n * wave) / S);  // rank of the junction column among the seeded ones
+            int b = 0;
+            unsigned long long mk = uni64(smask[0]);
+            while (__popcll(mk) <= t) { t -= __popcll(mk); ++b; mk = uni64(smask[b]); }
+            for (; t > 0; --t) mk &= mk - 1ull;
+            x = b * 64 + __ffsll((long long)mk) - 1;
+        }
+        float best = inf;
+        int bestu = 0;
+        auto eval_word = [&](int wd) {
+            unsigned long long mk = uni64(smask[wd]);
+            if (!mk) return;
+            const uint4 dv = dp[min(wd * 64 + lane, W - 1)];
+            while (mk) {
+                const int j = __ffsll((long long)mk) - 1;
+                mk &= mk - 1ull;
+                const int u = wd * 64 + j;
+                unsigned long long wc;
+                int pc, nc;
+                desc_lane4(dv, j, wc, pc, nc);
+                const float fu = column_value<true>(wc, pc, nc, lane, y);
+                const int du = u - x;
+                const float val = fu + (float)(du * du);
+                const bool better = val < best || (val == best && u < bestu);
+                best = better ? val : best;
+                bestu = better ? u : bestu;
+            }
+        };
+        const int wi = x >> 6;
+        for (int s = 0;; ++s) {
+            const int wr = wi + s, wl = wi - s;
+            // values are >= +0, so their bit patterns order like the values
+            const float mb = __int_as_float(__builtin_amdgcn_readfirstlane(wave_max(__float_as_int(best))));
+            bool doR = wr < nwords, doL = s > 0 && wl >= 0;
+            if (doR && s > 0) { const int d = wr * 64 - x; doR = (float)(d * d) <= mb; }
+            if (doL) { const int d = x - (wl * 64 + 63); doL = (float)(d * d) <= mb; }
+            if (!doR && !doL) break;
+            if (doR) eval_word(wr);
+            if (doL) eval_word(wl);
+        }
+        cj[wave][lane] = bestu;
+    }
+    __syncthreads();
+    // ---- phase B: the literal run over the columns (cs, ce] on a stack whose bottom is column cs
+    const int cs = wave == 0 ? 0 : cj[wave][lane];
+    int ce = wave == S - 1 ? W - 1 : cj[wave + 1][lane];
+    ce = max(ce, cs);
+    const uint4 db = dp[cs];
+    int tv = cs;
+    float tf = column_value<true>(((unsigned long long)db.y << 32) | db.x, (int)db.z, (int)db.w, lane, y);
+    float tz = -inf;
+    float tvf = (float)tv, tv2 = tvf * tvf, tvx2 = tvf + tvf;
+    int cnt = 0;   // entries below the top (indices 0..cnt-1); [base, cnt) in the LDS ring, [0, base) in HBM
+    int base = 0;
+    float minF = inf;
+    const int slot0 = cs + wave;  // segments of a row use disjoint slot ranges
+    auto evict = [&]() {
+        const int rb = base & (C - 1);
+        const size_t o = (size_t)(slot0 + base) * NR + r;
+        B.ev[o] = r_v[rb][tid]; B.ef[o] = r_f[rb][tid]; B.ez[o] = r_z[rb][tid];
+        ++base;
+    };
+    const int qlo = __builtin_amdgcn_readfirstlane(wave_min(cs)) + 1;
+    const int qhi = __builtin_amdgcn_readfirstlane(wave_max(ce));
+    if (qlo <= qhi) {
+        const int wlo = qlo >> 6, whi = qhi >> 6;
+        uint4 dreg = dp[min(wlo * 64 + lane, W - 1)];
+        for (int wd = wlo; wd <= whi; ++wd) {
+            const uint4 dnext = dp[min((wd + 1) * 64 + lane, W - 1)];  // in flight during this word
+            unsigned long long mk = uni64(smask[wd]);  // seedless columns are skipped (see k_pass2_l2)
+            if (wd == wlo) mk &= ~0ull << (qlo & 63);
+            if (wd == whi) mk &= ~0ull >> (63 - (qhi & 63));
+            while (mk) {
+                const int j = __ffsll((long long)mk) - 1;
+                mk &= mk - 1ull;
+                const int q = wd * 64 + j;
+                unsigned long long wc;
+                int pc, nc;
+                desc_lane4(dreg, j, wc, pc, nc);
+                const float fq = column_value<true>(wc, pc, nc, lane, y);
+                const bool act = q > cs && q <= ce;
+                const float qf = (float)q;
+                const float q2 = qf * qf;  // rounds like the reference's float(long(q * q))
+                const float hq = fq + q2;
+                const float twoq = qf + qf;
+                float s;
+                while (true) {
+                    // s = ((f[q] + q^2) - f[v] - v^2) / (2q - 2v), left to right in float (imgproc.h:111)
+                    const float N = (hq - tf) - tv2;
+                    s = N / (twoq - tvx2);
+                    const bool pop = act && !(s > tz) && cnt > 0;  // cnt > 0: the bottom (z = -inf) is never popped
+                    if (!__any(pop)) break;
+                    if (pop) {
+                        if (cnt == base) {  // ring empty: one spilled entry comes back (rare)
+                            --base;
+                            const int rb = base & (C - 1);
+                            const size_t o = (size_t)(slot0 + base) * NR + r;
+                            r_v[rb][tid] = B.ev[o]; r_f[rb][tid] = B.ef[o]; r_z[rb][tid] = B.ez[o];
+                        }
+                        --cnt;
+                        const int rr = cnt & (C - 1);
+                        tv = r_v[rr][tid]; tf = r_f[rr][tid]; tz = r_z[rr][tid];
+                        tvf = (float)tv; tv2 = tvf * tvf; tvx2 = tvf + tvf;
+                    }
+                }
+                if (act) {
+                    if (cnt == 0) minF = s < minF ? s : minF;  // a test against the bottom entry
+                    if (cnt - base == C) evict();
+                    const int rr = cnt & (C - 1);
+                    r_v[rr][tid] = tv; r_f[rr][tid] = tf; r_z[rr][tid] = tz;
+                    ++cnt;
+                    tv = q; tf = fq; tz = s; tv2 = q2; tvx2 = twoq;
+                }
+            }
+            dreg = dnext;
+        }
+    }
+    // the top joins the entries; everything still in the ring goes to HBM
+    if (cnt - base == C) evict();
+    {
+        const int rr = cnt & (C - 1);
+        r_v[rr][tid] = tv; r_f[rr][tid] = tf; r_z[rr][tid] = tz;
+        ++cnt;
+    }
+#pragma unroll
+    for (int e = 0; e < C; ++e) {
+        const int i = base + e;
+        if (i < cnt) {
+            const int rb = i & (C - 1);
+            const size_t o = (size_t)(slot0 + i) * NR + r;
+            B.ev[o] = r_v[rb][tid]; B.ef[o] = r_f[rb][tid]; B.ez[o] = r_z[rb][tid];
+        }
+    }
+    const size_t to = (size_t)wave * NR + r;
+    B.tcnt[to] = cnt; B.tminf[to] = minF; B.tslot[to] = slot0;
+}
+
+// Junction check + one walk over the concatenated stack of a row (lane = row).
+template <int KL>
+__global__ void __launch_bounds__(256) k_addend(int W, int S, int part_w, K2Buf B, int force_mod) {
+    __shared__ unsigned l_pk[KL][256];  // the last KL owner entries of each row
+    __shared__ float l_b[KL][256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long chunk = (long)blockIdx.x * 4 + wave;
+    const size_t NR = (size_t)B.NR;
+    if ((size_t)chunk * 64 >= NR) return;
+    const size_t r = (size_t)chunk * 64 + lane;
+    int pend_v = 0, pend_st = 0, last_st = -1, lc = 0, pi1 = 0, pi2 = 0, pi3 = 0;
+    float pend_f = 0.f, pend_z = 0.f;
+    bool have = false, ok = true;
+    // The pending entry owns the pixels [pend_st, st_next) if that range is not empty (owner of q = the last
+    // entry with z < q, imgproc.h:124).  Addend: f[v] if it takes over at or before its own column, else the
+    // value the reference reads back at v: g[v] = addend_o + (v - v_o)^2 with o the owner of pixel v.
+    auto finalize = [&](int st_next) {
+        if (pend_st < st_next && pend_st > last_st) {
+            float b = pend_f;
+            if (pend_st > pend_v) {
+                int o = lc - 1;
+                unsigned pk;
+                float bo;
+                while (true) {
+                    if (o >= lc - KL) {
+                        pk = l_pk[o & (KL - 1)][tid]; bo = l_b[o & (KL - 1)][tid];
+                    } else {  // older than the LDS window (rare): from the list in HBM, consumed in place
+                        const unsigned a0 = B.lpk[(size_t)o * NR + r];
+                        const float a1 = B.lb[(size_t)o * NR + r];
+                        asm volatile("v_mov_b32 %0, %1" : "=v"(pk) : "v"(a0));
+                        asm volatile("v_mov_b32 %0, %1" : "=v"(bo) : "v"(a1));
+                    }
+                    if ((int)(pk >> 16) <= pend_v || o == 0) break;
+                    --o;
+                }
+                const float dv = (float)(pend_v - (int)(pk & 0xffffu));  // dv * dv rounds like float(long(dv * dv))
+                b = bo + dv * dv;
+            }
+            const unsigned npk = ((unsigned)pend_st << 16) | (unsigned)pend_v;
+            l_pk[lc & (KL - 1)][tid] = npk; l_b[lc & (KL - 1)][tid] = b;
+            B.lpk[(size_t)lc * NR + r] = npk; B.lb[(size_t)lc * NR + r] = b;
+            if (pend_st <= part_w) pi1 = lc;
+            if (pend_st <= 2 * part_w) pi2 = lc;
+            if (pend_st <= 3 * part_w) pi3 = lc;
+            last_st = pend_st;
+            ++lc;
+        }
+    };
+    for (int w = 0; w < S; ++w) {
+        const size_t to = (size_t)w * NR + r;
+        const int n = B.tcnt[to], slot0 = B.tslot[to];
+        const float mf = B.tminf[to];
+        // every test against this segment's bottom column must also push on the real stack, where that column
+        // is the previous segment's top with z = pend_z
+        if (w > 0) ok = ok && mf > pend_z && pend_v == slot0 - w;
+        const int nmax = __builtin_amdgcn_readfirstlane(wave_max(n));
+        for (int e0 = w ? 1 : 0; e0 < nmax; e0 += 8) {  // entry 0 of a later segment repeats the previous top
+            int vv[8];
+            float ff[8], zz[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const size_t o = (size_t)(slot0 + min(e0 + u, n - 1)) * NR + r;
+                vv[u] = B.ev[o]; ff[u] = B.ef[o]; zz[u] = B.ez[o];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (e0 + u < n) {
+                    const float z = zz[u];
+                    // first pixel above z: the entry takes over there (while (z[k+1] < q) ++k)
+                    const int st = z < 0.f ? 0 : (!(z < (float)W) ? W : (int)floorf(z) + 1);
+                    if (have) finalize(st);
+                    pend_v = vv[u]; pend_f = ff[u]; pend_z = z; pend_st = st; have = true;
+                }
+            }
+        }
+    }
+    if (have) finalize(W);
+    B.lcount[r] = lc;
+    B.partidx[r] = pi1; B.partidx[NR + r] = pi2; B.partidx[2 * NR + r] = pi3;
+    const bool forced = force_mod > 0 && chunk % force_mod == 0;  // test hook: exercise the redo path
+    if ((__any(!ok) || forced) && lane == 0) B.flags[chunk] = 1;
+}
+
+// Pure fill (imgproc.h:122-128) from the owner list; wave p of a block fills the pixels
+// [p * part_w, (p + 1) * part_w) of the block's 64 rows, writes to column q are coalesced.
+template <int RE>
+__global__ void __launch_bounds__(256) k_fill(float* __restrict__ vol, int W, int H, int HW64, int part_w, K2Buf B) {
+    __shared__ unsigned f_pk[RE][256];
+    __shared__ float f_b[RE][256];
+    const int tid = threadIdx.x, lane = tid & 63, p = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long chunk = blockIdx.x;
+    const long k = chunk / HW64;
+    const int c = (int)(chunk - k * HW64);
+    const int y = c * 64 + lane;
+    const size_t NR = (size_t)B.NR;
+    const size_t r = (size_t)chunk * 64 + lane;
+    int qcur = p * part_w;
+    const int qend = min(qcur + part_w, W);
+    if (qcur >= qend) return;
+    int idx = p == 0 ? 0 : B.partidx[(size_t)(p - 1) * NR + r];
+    const int lc = B.lcount[r];
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc(vol + (size_t)k * W * H, 0, (unsigned)((size_t)W * H * 4), 0x00020000);
+    const unsigned vrow = y < H ? (unsigned)y * 4u : 0x80000000u;  // rows past the image: dropped stores
+    const int colB = H * 4;
+    while (qcur < qend) {
+        // entries [idx, idx + RE) of every row go to LDS; the round ends where the first row would need entry idx + RE
+        unsigned pk[RE];
+        float bb[RE];
+#pragma unroll
+        for (int e = 0; e < RE; ++e) {
+            const size_t o = (size_t)min(idx + e, lc - 1) * NR + r;
+            pk[e] = B.lpk[o]; bb[e] = B.lb[o];
+        }
+#pragma unroll
+        for (int e = 0; e < RE; ++e) {
+            if (idx + e >= lc) pk[e] = 0x7fff0000u;  // past the list: never taken over
+            f_pk[e][tid] = pk[e]; f_b[e][tid] = bb[e];
+        }
+        const int lim = (int)(pk[RE - 1] >> 16);
+        const int qstop = min(qend, __builtin_amdgcn_readfirstlane(wave_min(lim)));
+        unsigned cpk = pk[0], npk = pk[1];
+        float cb = bb[0], nb = bb[1];
+        int a = 0;
+        for (int q = qcur; q < qstop; ++q) {
+            const bool adv = q >= (int)(npk >> 16);
+            if (adv) { cpk = npk; cb = nb; ++a; }
+            npk = f_pk[a + 1][tid]; nb = f_b[a + 1][tid];  // a + 1 <= RE - 1 because q < lim
+            const float dq = (float)(q - (int)(cpk & 0xffffu));  // dq * dq rounds like float(long(dq * dq))
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(cb + dq * dq), rs, vrow, q * colB, 0);
+        }
+        idx += a;
+        qcur = qstop;
     }
 }
 
@@ -805,12 +1167,45 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after) {
     fm->vol.reserve(nvox * sizeof(float));
     fm->bitmap.reserve((size_t)ncols * HW64 * 8);
     const long nchunks = (long)m * HW64;  // (slice, 64-row chunk) pairs
-    int R = 64;                            // rows per wave of the L2 sweep: keep >= 2048 waves in flight
-    while (R > 16 && nchunks * (64 / R) < 2048) R >>= 1;
-    if (const char* e = getenv("FDCM_K2_ROWS")) R = atoi(e);  // tuning override (16, 32 or 64)
+    // Tuning overrides, read once (measurements and tests only).
+    static const int env_rows = getenv("FDCM_K2_ROWS") ? atoi(getenv("FDCM_K2_ROWS")) : 0;
+    static const int env_lean = getenv("FDCM_K2_LEAN") ? atoi(getenv("FDCM_K2_LEAN")) : -1;
+    static const bool env_serial_fill = getenv("FDCM_K2_SERIAL_FILL") != nullptr;
+    static const bool env_legacy = getenv("FDCM_K2_LEGACY") != nullptr;            // one-wave-per-chunk kernel only
+    static const int env_segments = getenv("FDCM_K2_SEGMENTS") ? atoi(getenv("FDCM_K2_SEGMENTS")) : 0;
+    static const int env_force_redo = getenv("FDCM_K2_FORCE_REDO") ? atoi(getenv("FDCM_K2_FORCE_REDO")) : 0;
+    const bool segmented = fm->distance != FDCM_L1 && !env_legacy;
+    int R = 64;                            // rows per wave of the one-wave-per-chunk L2 sweep: keep >= 2048 waves in flight
+    if (!segmented) {
+        while (R > 16 && nchunks * (64 / R) < 2048) R >>= 1;
+        if (env_rows == 16 || env_rows == 32 || env_rows == 64) R = env_rows;
+    }
     const long nwaves = fm->distance == FDCM_L1 ? nchunks : nchunks * (64 / R);
+    // segments per row of the segmented sweep: small images need the split most (few rows), but a segment
+    // should still hold a few dozen columns
+    int S = W >= 128 ? 4 : (W >= 64 ? 2 : 1);
+    if (env_segments >= 1 && env_segments <= kSegMax) S = env_segments;
+    const int part_w = (W + kFillParts - 1) / kFillParts;
     fm->coldesc.reserve((size_t)ncols * HW64 * sizeof(ColDesc));
-    if (fm->distance != FDCM_L1) fm->stack.reserve((size_t)W * nwaves * R * 12);
+    K2Buf kb{};
+    if (fm->distance != FDCM_L1) {
+        // scratch of the L2 sweeps: envelope entries (W + kSegMax + 2 slots per row, 12 B), owner list (W + 2
+        // entries per row, 8 B), per-segment and per-row records, chunk flags
+        const size_t NRr = (size_t)nchunks * 64, slots = (size_t)W + kSegMax + 2, lslots = (size_t)W + 2;
+        size_t off = 0;
+        auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+        const size_t o_ev = take(slots * NRr * 4), o_ef = take(slots * NRr * 4), o_ez = take(slots * NRr * 4);
+        const size_t o_lpk = take(lslots * NRr * 4), o_lb = take(lslots * NRr * 4);
+        const size_t o_tc = take(kSegMax * NRr * 4), o_tm = take(kSegMax * NRr * 4), o_ts = take(kSegMax * NRr * 4);
+        const size_t o_lc = take(NRr * 4), o_pi = take(3 * NRr * 4), o_fl = take((size_t)nchunks * 4);
+        fm->stack.reserve(off);
+        char* sb = (char*)fm->stack.p;
+        kb.ev = (int*)(sb + o_ev); kb.ef = (float*)(sb + o_ef); kb.ez = (float*)(sb + o_ez);
+        kb.lpk = (unsigned*)(sb + o_lpk); kb.lb = (float*)(sb + o_lb);
+        kb.tcnt = (int*)(sb + o_tc); kb.tminf = (float*)(sb + o_tm); kb.tslot = (int*)(sb + o_ts);
+        kb.lcount = (int*)(sb + o_lc); kb.partidx = (int*)(sb + o_pi); kb.flags = (int*)(sb + o_fl);
+        kb.NR = (long)NRr;
+    }
     // ---- plan upload: one pinned blob, one async copy
     auto align16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
     fm->off_raster = 0;
@@ -859,23 +1254,33 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after) {
                 hipLaunchKernelGGL(k_l1_backward, dim3((unsigned)((bwaves + 3) / 4)), dim3(256), 0, st, vol, W, H, nrows);
             }
         } else {
-            const size_t NT = (size_t)nwaves * R;
-            int* sv = fm->stack.as<int>();
-            float* sf = (float*)(sv + (size_t)W * NT);
-            float* sz = sf + (size_t)W * NT;
-            // LDS per block = (3 C + 3 SG) * 4R * 4 B + 4 KiB; a CU holds 160 KiB.  Small grids get the long
-            // ring (fewer HBM round trips in the fill), large grids the short one (all waves resident).
-            bool small_grid = nwaves <= 2048;
-            if (const char* e = getenv("FDCM_K2_LEAN")) small_grid = atoi(e) == 0;  // tuning override
-#define FDCM_K2(RR, CC, SS, PP) hipLaunchKernelGGL((k_pass2_l2<RR, CC, SS, PP>), dim3(wblocks), dim3(256), 0, st, d_desc, vol, W, H, HW64, nwaves, sv, sf, sz)
-            static const bool no_pf = getenv("FDCM_K2_SERIAL_FILL") != nullptr;  // tuning override
-            if (R == 64) { if (small_grid) FDCM_K2(64, 16, 8, false); else FDCM_K2(64, 8, 4, false); }
-            else if (R == 32) {
-                if (small_grid && !no_pf) FDCM_K2(32, 32, 8, true); else if (small_grid) FDCM_K2(32, 32, 16, false);
-                else if (!no_pf) FDCM_K2(32, 16, 4, true); else FDCM_K2(32, 16, 8, false);
+            // the one-wave-per-chunk kernel uses the entry arrays as its (v, f, z) scratch: [W][nwaves * R] each
+            int* sv = kb.ev;
+            float* sf = kb.ef;
+            float* sz = kb.ez;
+            const int* gate = nullptr;
+#define FDCM_K2(RR, CC, SS, PP) hipLaunchKernelGGL((k_pass2_l2<RR, CC, SS, PP>), dim3(wblocks), dim3(256), 0, st, d_desc, vol, W, H, HW64, nwaves, sv, sf, sz, gate)
+            if (segmented) {
+                hipLaunchKernelGGL(k_env<16>, dim3((unsigned)nchunks), dim3(64 * S), 0, st, d_desc, W, H, HW64, S, kb);
+                hipLaunchKernelGGL(k_addend<8>, dim3((unsigned)((nchunks + 3) / 4)), dim3(256), 0, st, W, S, part_w, kb, env_force_redo);
+                hipLaunchKernelGGL(k_fill<16>, dim3((unsigned)nchunks), dim3(256), 0, st, vol, W, H, HW64, part_w, kb);
+                // chunks whose junction check failed are redone literally, one wave per chunk (all others exit at once)
+                gate = kb.flags;
+                FDCM_K2(64, 8, 4, false);
             } else {
-                if (small_grid && !no_pf) FDCM_K2(16, 64, 4, true); else if (small_grid) FDCM_K2(16, 64, 16, false);
-                else if (!no_pf) FDCM_K2(16, 32, 4, true); else FDCM_K2(16, 32, 8, false);
+                // LDS per block = (3 C + 3 SG) * 4R * 4 B + 4 KiB; a CU holds 160 KiB.  Small grids get the long
+                // ring (fewer HBM round trips in the fill), large grids the short one (all waves resident).
+                bool small_grid = nwaves <= 2048;
+                if (env_lean >= 0) small_grid = env_lean == 0;
+                const bool no_pf = env_serial_fill;
+                if (R == 64) { if (small_grid) FDCM_K2(64, 16, 8, false); else FDCM_K2(64, 8, 4, false); }
+                else if (R == 32) {
+                    if (small_grid && !no_pf) FDCM_K2(32, 32, 8, true); else if (small_grid) FDCM_K2(32, 32, 16, false);
+                    else if (!no_pf) FDCM_K2(32, 16, 4, true); else FDCM_K2(32, 16, 8, false);
+                } else {
+                    if (small_grid && !no_pf) FDCM_K2(16, 64, 4, true); else if (small_grid) FDCM_K2(16, 64, 16, false);
+                    else if (!no_pf) FDCM_K2(16, 32, 4, true); else FDCM_K2(16, 32, 8, false);
+                }
             }
 #undef FDCM_K2
         }

@@ -546,7 +546,10 @@ __global__ void __launch_bounds__(1024) k_scatter(const fdcm_match* __restrict__
 
 int64_t search_capacity(const fdcm_templates* t, int64_t n_scene, int64_t maxT, int64_t maxS) {
     int64_t total = 0;
-    const int64_t window = std::min<int64_t>(maxS, n_scene);
+    // the reference takes size_t limits and applies min(tmpl.cols(), maxTmplLines) / min(scene, maxSceneLines)
+    // (defaultsearch.cpp:38, defaultsearch.h:42-46): "all lines" values such as 2^40 are legal
+    maxT = std::min<int64_t>(std::max<int64_t>(maxT, 0), std::max<int64_t>(t->max_lines, 0));
+    const int64_t window = std::min<int64_t>(std::max<int64_t>(maxS, 0), n_scene);
     for (int64_t i = 0; i < t->T; ++i) {
         const int64_t nt = t->offsets[i + 1] - t->offsets[i];
         total += 2 * std::min<int64_t>(nt, maxT) * window;
@@ -569,7 +572,11 @@ void run_search(fdcm_featuremap* fm, const fdcm_templates* t, const float* scene
     }
     hipStream_t st = fm->stream;
     const int n_s = (int)n_scene;
-    const int window = (int)std::min<int64_t>(maxS, n_scene);
+    // Clamp the limits before any cast or sizing: the reference takes size_t and applies min() (defaultsearch.cpp:38,
+    // defaultsearch.h:42-46), so DefaultSearch(10**12, 10**12) means "all lines".
+    maxT = std::min<int64_t>(std::max<int64_t>(maxT, 0), std::max<int64_t>(t->max_lines, 0));
+    maxS = std::min<int64_t>(std::max<int64_t>(maxS, 0), n_scene);
+    const int window = (int)maxS;
     // ---- scene side of establishSearchStrategy (defaultsearch.cpp:32-36): lengths, argsort by
     // descending length with std::sort (same comparator and index type as the reference)
     std::vector<float> slen((size_t)n_s);

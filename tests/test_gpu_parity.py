@@ -160,6 +160,13 @@ def test_search_edge_cases(amd):
     want = O.search(orc, tl, scene, 4, 10, kind=O.BATCH_OPTIMIZE, batch=10)
     assert assert_matches_close(got, want, "ragged templates")
     assert set(np.unique(got["tmpl_idx"])) <= {0, 2, 3}
+    # "all lines" limits: max_tmpl_lines is a size_t under min() (defaultsearch.cpp:38), max_scene_lines goes through
+    # int casts (defaultsearch.h:42-46) and is well defined up to 2^31 - 1; both mean "every line" here
+    big_t, big_s = 2 ** 40, 2 ** 31 - 1
+    got = search_raw(dev, DeviceTemplates(tl), scene, big_t, big_s, O.BATCH_OPTIMIZE, 10)
+    want = O.search(orc, tl, scene, big_t, big_s, kind=O.BATCH_OPTIMIZE, batch=10)
+    assert len(want) > 200 and assert_matches_close(got, want, "unbounded search window")
+    assert DeviceTemplates(tl).capacity(10, big_t, big_s) == 2 * (10 + 0 + 3 + 1) * 10
     # degenerate lines: zero-length scene line and zero-length template line
     sc2 = np.concatenate([scene, np.array([[5], [5], [5], [5]], dtype=np.float32)], axis=1)
     t2 = np.concatenate([tmpl, np.array([[1], [1], [1], [1]], dtype=np.float32)], axis=1)
@@ -305,17 +312,89 @@ def test_frame_pipeline_device_buffers_and_errors(amd):
     pipe.close()
 
 
-# ---------------------------------------------------------------- BASELINE configs 3 and 5
-def test_config3_build_and_search(amd):
-    """Config 3: 2048^2, depth 60, L2_SQUARED -- the whole 1 GB volume bit for bit (compared slice by slice)
-    and the match list of the first 200 templates."""
+# ---------------------------------------------------------------- BASELINE configs 1, 2', 3, 4 (per-GPU shape), 5
+def _mem_available_gb():
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                return int(line.split()[1]) / 1e6
+    except OSError:
+        pass
+    return 0.0
+
+
+def test_config1_full_size_assets(amd):
+    """Config 1 at full size (notebooks/general_template_matching_example.ipynb:275-306 on the line files shipped
+    beside it): obj_04/scene_0 (646 lines, 487 x 487 feature map), all 122 templates, depth 30,
+    coeff 5, L2, padding 1.0.  Whole volume bit for bit; match lists for DefaultSearch(4,4) + BatchOptimize(10) and
+    for the notebook's own DefaultSearch(3,10) + BatchOptimize(5); the notebook's tail (ExponentialPenalty(1.5) +
+    sort + first 30) on the device against the product's host tail."""
+    import os
+    import ctypes as C
+    from helpers import ROOT
+    from openfdcm_amd import lineio, _capi
+    from openfdcm_amd.engine import DeviceFeatureMap, DeviceTemplates, search_raw, topk
+    d = os.path.join(ROOT, "tests", "golden", "obj_04")
+    scene = lineio.read(os.path.join(d, "scene_0.scene"))
+    tmpls = [lineio.read(os.path.join(d, f"template_{i}.tmpl")) for i in range(122)]
+    assert scene.shape == (4, 646) and min(t.shape[1] for t in tmpls) >= 12 and max(t.shape[1] for t in tmpls) <= 31
+    dev = DeviceFeatureMap.build(scene, depth=30, coeff=5.0, padding=1.0, distance=O.L2)
+    orc = O.build(scene, depth=30, coeff=5.0, padding=1.0, distance=O.L2, nthreads=8)
+    assert (dev.width, dev.height, dev.depth) == (487, 487, 30) == (orc.W, orc.H, orc.depth)
+    assert np.array_equal(dev.scene_translation, orc.translation)
+    assert_volume_equal(dev, orc, "config 1")
+    tset = DeviceTemplates(tmpls)
+    for maxT, maxS, B in [(4, 4, 10), (3, 10, 5)]:
+        got = search_raw(dev, tset, scene, maxT, maxS, O.BATCH_OPTIMIZE, B)
+        want = O.search(orc, tmpls, scene, maxT, maxS, kind=O.BATCH_OPTIMIZE, batch=B, nthreads=8)
+        assert len(want) > 3000
+        assert assert_matches_close(got, want, f"config 1 DefaultSearch({maxT},{maxS})"), "not bit-identical"
+    # tail of the notebook: penalize(ExponentialPenalty(1.5)) + sort_matches + [:30]
+    rec = np.array(got, copy=True)
+    lens = tset.lengths()
+    _capi.check(_capi.lib().fdcm_penalize(1, 1.5, C.c_void_p(rec.ctypes.data), len(rec), _capi.fptr(lens), len(lens)))
+    want_tail = rec[np.argsort(rec["score"], kind="stable")[:30]]
+    assert topk(dev, tset, 30, 1, 1.5).tobytes() == want_tail.tobytes()
+
+
+def test_config2p_match_list_1000_templates(amd):
+    """Config 2' (the headline of BASELINE.json:metric): 1024^2, depth 30, L2, 1000 templates x 32 lines -- the whole
+    match list against the oracle."""
     import os
     from openfdcm_amd import synthetic
     from openfdcm_amd.engine import DeviceFeatureMap, DeviceTemplates, search_raw
-    c, scene, tmpls = synthetic.make_config("3", T=200)
+    c, scene, tmpls = synthetic.make_config("2p")
     nt = min(32, os.cpu_count() or 1)
     dev = DeviceFeatureMap.build(scene, depth=c["depth"], coeff=5.0, padding=1.0, distance=c["distance"])
     orc = O.build(scene, depth=c["depth"], coeff=5.0, padding=1.0, distance=c["distance"], nthreads=nt)
+    got = search_raw(dev, DeviceTemplates(tmpls), scene, 4, 4, O.BATCH_OPTIMIZE, 10)
+    want = O.search(orc, tmpls, scene, 4, 4, kind=O.BATCH_OPTIMIZE, batch=10, nthreads=nt)
+    assert len(tmpls) == 1000 and len(want) > 20000
+    assert assert_matches_close(got, want, "config 2'"), "not bit-identical"
+
+
+@pytest.fixture(scope="module")
+def config3_maps(amd):
+    """Configs 3 and 4 share the scene: 2048^2, depth 60, L2_SQUARED (1 GB volume), built once on both sides."""
+    import os
+    from openfdcm_amd import synthetic
+    from openfdcm_amd.engine import DeviceFeatureMap
+    c = synthetic.CONFIGS["3"]
+    scene = synthetic.scene(c["S"], c["scene_lines"], 1)
+    nt = min(32, os.cpu_count() or 1)
+    dev = DeviceFeatureMap.build(scene, depth=c["depth"], coeff=5.0, padding=1.0, distance=c["distance"])
+    orc = O.build(scene, depth=c["depth"], coeff=5.0, padding=1.0, distance=c["distance"], nthreads=nt)
+    yield c, scene, dev, orc, nt
+    dev.close()
+
+
+def test_config3_build_and_search(amd, config3_maps):
+    """Config 3: 2048^2, depth 60, L2_SQUARED -- the whole 1 GB volume bit for bit (compared slice by slice)
+    and the match list of the first 200 templates."""
+    from openfdcm_amd import synthetic
+    from openfdcm_amd.engine import DeviceTemplates, search_raw
+    c, scene, dev, orc, nt = config3_maps
+    tmpls = synthetic.templates(200, c["n"], c["S"], 2)
     assert (dev.width, dev.height, dev.depth) == (2048, 2048, 60) == (orc.W, orc.H, orc.depth)
     for k in range(dev.depth):
         a, b = dev.slice(k), orc.slice(k)
@@ -327,22 +406,48 @@ def test_config3_build_and_search(amd):
     assert assert_matches_close(got, want, "config 3"), "not bit-identical"
 
 
-@pytest.mark.slow
-def test_config5_sampled_slices(amd):
-    """Config 5 (stress): 4096^2, depth 180, L1 -- a 12 GB volume; seven slices compared bit for bit.
-    Needs ~30 GB of host memory for the oracle's volume; set FDCM_TEST_STRESS=1 to run."""
-    import os
-    if os.environ.get("FDCM_TEST_STRESS") != "1":
-        pytest.skip("stress case: set FDCM_TEST_STRESS=1")
+def test_config4_per_gpu_shard(amd, config3_maps):
+    """Config 4's per-GPU shape on one GPU: 2048^2, depth 60, L2_SQUARED, the shard of rank 1 of 8 -- templates
+    1000..1999 of the 8000, tmpl_index_base 1000 -- against the oracle's list for the same templates."""
     from openfdcm_amd import synthetic
-    from openfdcm_amd.engine import DeviceFeatureMap
+    from openfdcm_amd.dist import shard_range
+    from openfdcm_amd.engine import DeviceTemplates, search_raw
+    c, scene, dev, orc, nt = config3_maps
+    all_t = synthetic.templates(2000, c["n"], c["S"], 2)  # the generator is a stream: the first 2000 of the 8000
+    lo, hi = shard_range(8000, 1, 8)
+    assert (lo, hi) == (1000, 2000)
+    shard = all_t[lo:hi]
+    got = search_raw(dev, DeviceTemplates(shard), scene, 4, 4, O.BATCH_OPTIMIZE, 10, lo)
+    want = O.search(orc, shard, scene, 4, 4, kind=O.BATCH_OPTIMIZE, batch=10, nthreads=nt)
+    want = np.array(want, copy=True)
+    want["tmpl_idx"] += lo
+    assert len(want) > 20000 and got["tmpl_idx"].min() >= lo and got["tmpl_idx"].max() < hi
+    assert assert_matches_close(got, want, "config 4 shard 1/8"), "not bit-identical"
+
+
+def test_config5_sampled_slices(amd):
+    """Config 5 (stress): 4096^2, depth 180, L1 -- a 12 GB volume; seven slices compared bit for bit, and the match
+    list of 64 templates x 32 lines searched the way a shard is (tmpl_index_base 6000).  The oracle's
+    volume needs ~30 GB of host memory: runs when MemAvailable >= 48 GB (always on the GPU box)."""
+    import os
+    if _mem_available_gb() < 48 and os.environ.get("FDCM_TEST_STRESS") != "1":
+        pytest.skip("needs 48 GB of free host memory for the oracle's 12 GB volume")
+    from openfdcm_amd import synthetic
+    from openfdcm_amd.engine import DeviceFeatureMap, DeviceTemplates, search_raw
     c = synthetic.CONFIGS["5"]
     scene = synthetic.scene(c["S"], c["scene_lines"], 1)
+    nt = os.cpu_count() or 1
     dev = DeviceFeatureMap.build(scene, depth=c["depth"], coeff=5.0, padding=1.0, distance=c["distance"])
-    orc = O.build(scene, depth=c["depth"], coeff=5.0, padding=1.0, distance=c["distance"], nthreads=os.cpu_count())
+    orc = O.build(scene, depth=c["depth"], coeff=5.0, padding=1.0, distance=c["distance"], nthreads=nt)
     for k in sorted(set(np.linspace(0, dev.depth - 1, 7).astype(int))):
         a, b = dev.slice(int(k)), orc.slice(int(k))
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"config 5 slice {k}"
+    tmpls = synthetic.templates(64, c["n"], c["S"], 5)
+    got = search_raw(dev, DeviceTemplates(tmpls), scene, 4, 4, O.BATCH_OPTIMIZE, 10, 6000)
+    want = np.array(O.search(orc, tmpls, scene, 4, 4, kind=O.BATCH_OPTIMIZE, batch=10, nthreads=nt), copy=True)
+    want["tmpl_idx"] += 6000
+    assert len(want) > 500
+    assert assert_matches_close(got, want, "config 5 shard"), "not bit-identical"
 
 
 # ---------------------------------------------------------------- device tail (include/fdcm.h, fdcm_topk)
