@@ -14,7 +14,9 @@
 //   K4 k_integral   directional prefix sum per slice, one sequential float chain per lane;
 //                   shallow and steep sweeps (the latter through LDS tiles) in one launch  read V, write V
 // Compiled with -ffp-contract=off; divide and sqrt are the correctly rounded forms.
+#include <algorithm>
 #include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -75,11 +77,16 @@ __device__ __forceinline__ int wave_min(int v) {
 // Column-chunk descriptor: for column (k, x) and the 64 rows [64c, 64c+64): the seed bits of the
 // chunk, the last seed row before it and the first seed row after it.  16 bytes per 64 pixels,
 // stored [k][c][x] so that a wave sweeping along x prefetches 64 columns with one coalesced load.
+static constexpr int kFar = 1 << 30;  // "no seed on that side": a row 2^30 away (rows are < 2^14)
 struct __attribute__((aligned(16))) ColDesc {
     unsigned long long word;
-    int prev;  // INT_MIN: none
-    int next;  // INT_MAX: none
+    int prev;  // -kFar: none
+    int next;  // +kFar: none
 };
+// a column without any seed in the slice (all its chunks say the same)
+__device__ __forceinline__ bool desc_seedless(const uint4& d) {
+    return (d.x | d.y) == 0u && (int)d.z == -kFar && (int)d.w == kFar;
+}
 
 // The seed words are cleared as they are read (when one pass reads each word once), so the next build of
 // the same size starts from a zero bitmap without a separate fill.
@@ -106,8 +113,10 @@ __global__ void __launch_bounds__(256) k_coldesc(unsigned long long* __restrict_
         }
         ColDesc d;
         d.word = word;
-        d.prev = max(wave_scan_max_excl(last_i, lane), carry_prev);
-        d.next = min(wave_scan_min_excl_rev(first_i, lane), carry_next);
+        const int pv = max(wave_scan_max_excl(last_i, lane), carry_prev);
+        const int nx = min(wave_scan_min_excl_rev(first_i, lane), carry_next);
+        d.prev = pv == INT_MIN ? -kFar : pv;
+        d.next = nx == INT_MAX ? kFar : nx;
         if (wi < HW64) desc[((size_t)k * HW64 + wi) * W + x] = d;
         carry_prev = max(carry_prev, wave_max(last_i));
     }
@@ -120,19 +129,15 @@ __global__ void __launch_bounds__(256) k_coldesc(unsigned long long* __restrict_
 // gives the reference's bits.  y = 64c + lane.
 template <bool SQUARED>
 __device__ __forceinline__ float column_value(unsigned long long wc, int pc, int nc, int lane, int y) {
-    // branch-free: a missing neighbour chunk seed becomes a position 2^30 away, so "no seed in the
-    // column" is d >= 2^29 (rows are < 2^24)
-    constexpr int FAR = 1 << 30;
-    const int pe = pc == INT_MIN ? -FAR : pc, ne = nc == INT_MAX ? FAR : nc;  // uniform per column
-    const unsigned long long below = wc & (~0ull >> (63 - lane));  // bits 0..lane
-    const unsigned long long above = wc & (~0ull << lane);          // bits lane..63
-    const int d_in_up = lane - (63 - __clzll(below | 1ull));         // | 1: defined for below == 0 (unused then)
-    const int d_in_dn = __ffsll((long long)(above | (1ull << 63))) - 1 - lane;
-    const int d_up = below ? d_in_up : y - pe;
-    const int d_dn = above ? d_in_dn : ne - y;
+    // branch-free: a missing neighbour chunk seed is a position 2^30 away (the descriptor says so), so "no seed
+    // in the column" is d >= 2^29 (rows are < 2^14)
+    const unsigned long long dnw = wc >> lane;         // bit 0 = own row, upwards = rows below it in the image
+    const unsigned long long upw = wc << (63 - lane);  // bit 63 = own row
+    const int d_dn = dnw ? __ffsll((long long)dnw) - 1 : nc - y;
+    const int d_up = upw ? __clzll(upw) : y - pc;
     const int d = min(d_up, d_dn);
     const float df = (float)d;
-    return d >= (1 << 29) ? FLT_MAX : (SQUARED ? df * df : df);  // d < 2^12: df * df is the exact integer
+    return d >= (1 << 29) ? FLT_MAX : (SQUARED ? df * df : df);  // d < 2^14: df * df is the exact integer
 }
 
 __device__ __forceinline__ void desc_lane(const ColDesc& d, int j, unsigned long long& wc, int& pc, int& nc) {
@@ -248,7 +253,7 @@ __global__ void __launch_bounds__(256) k_pass2_l2(const ColDesc* __restrict__ de
     uint4 dreg = dp[min(lane, W - 1)];
     for (int q0 = 0; q0 < W; q0 += 64) {
         // lane j holds the descriptor of column q0 + j: one ballot tells which columns are seedless
-        const bool sl = (dreg.x | dreg.y) == 0u && (int)dreg.z == INT_MIN && (int)dreg.w == INT_MAX;
+        const bool sl = desc_seedless(dreg);
         const unsigned long long smask = __ballot(sl);
         dsc[wave][lane] = dreg;                    // the only wait on vector memory per 64 columns
         dreg = dp[min(q0 + 64 + lane, W - 1)];     // next 64 descriptors, in flight during this chunk
@@ -468,17 +473,23 @@ __global__ void __launch_bounds__(256) k_pass2_l2(const ColDesc* __restrict__ de
 //             imgproc.h:126-127), re-evaluated from the owner of pixel v found a few entries back
 //   k_fill    lane = (row, quarter of the pixels): pure fill from the owner list, entries staged through
 //             LDS in rounds of RE
-static constexpr int kSegMax = 4;
+static constexpr int kSegMax = 8;
 static constexpr int kFillParts = 4;
 
+// Row-major scratch: every lane streams through its own row's records (the positions differ from row to row, so a
+// [slot][row] layout would scatter the lanes of one access over as many pages as rows).
+struct EnvEntry { int v; float f; float z; };       // one stack entry (imgproc.h: v[k], f[v[k]], z[k])
+struct OwnEntry { unsigned pk; float b; };          // (first pixel << 16 | column), addend
 struct K2Buf {
-    int* ev; float* ef; float* ez;        // envelope entries [slot][row]
-    unsigned* lpk; float* lb;             // owner list [index][row]: (first pixel << 16 | column), addend
+    EnvEntry* ent;                        // envelope entries [row][slot], eslots per row
+    OwnEntry* own;                        // owner list [row][index], lslots per row
     int* tcnt; float* tminf; int* tslot;  // per (segment, row): entries, min s against the bottom, first slot
     int* lcount;                          // owner entries per row
     int* partidx;                         // [part - 1][row]: list index that owns the first pixel of fill part 1..3
     int* flags;                           // per 64-row chunk: 1 = redo with k_pass2_l2
+    long long* dbg;                       // optional per-wave clock stamps and counters (FDCM_K2_DEBUG), else null
     long NR;                              // rows of the scratch arrays (chunks * 64)
+    int eslots, lslots;
 };
 
 __device__ __forceinline__ unsigned long long uni64(unsigned long long v) {
@@ -494,13 +505,11 @@ __device__ __forceinline__ void desc_lane4(const uint4& d, int j, unsigned long 
     nc = __builtin_amdgcn_readlane((int)d.w, j);
 }
 
-template <int C>
-__global__ void __launch_bounds__(256) k_env(const ColDesc* __restrict__ desc, int W, int H, int HW64, int S, K2Buf B) {
+template <int C, int NT, int GW, bool DBG>
+__global__ void __launch_bounds__(NT) k_env(const ColDesc* __restrict__ desc, int W, int H, int HW64, int S, K2Buf B, int expm) {
     __shared__ unsigned long long smask[256];  // seeded columns of the slice, 64 per word (W <= 16384)
-    __shared__ int cj[kSegMax + 1][64];        // junction column of segment w per row
-    __shared__ int r_v[C][256];
-    __shared__ float r_f[C][256];
-    __shared__ float r_z[C][256];
+    __shared__ int cj[NT / 64 + 1][64];        // junction column of segment w per row
+    __shared__ float4 ring[C][NT];             // stack entries below the top: (float(v), f[v], z, float(v)^2)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const long chunk = blockIdx.x;
     const long k = chunk / HW64;
@@ -511,15 +520,19 @@ __global__ void __launch_bounds__(256) k_env(const ColDesc* __restrict__ desc, i
     const uint4* dp = reinterpret_cast<const uint4*>(desc + ((size_t)k * HW64 + c) * W);
     const int nwords = (W + 63) >> 6;
     const float inf = f_inf();
+    long long* dbg = DBG ? B.dbg + ((size_t)chunk * kSegMax + wave) * 16 : nullptr;
+    long long n_cols = 0, n_iter = 0, n_evict = 0, n_refill = 0, n_eval = 0;
+    long long sc0 = 0;
+    if (DBG && lane == 0) { dbg[0] = wall_clock64(); sc0 = clock64(); }
     if (tid == 0) B.flags[chunk] = 0;
     for (int b = wave; b < nwords; b += S) {
         const int x = b * 64 + lane;
         const uint4 d = dp[min(x, W - 1)];
-        const bool seeded = x < W && !((d.x | d.y) == 0u && (int)d.z == INT_MIN && (int)d.w == INT_MAX);
-        const unsigned long long mk = __ballot(seeded);
+        const unsigned long long mk = __ballot(x < W && !desc_seedless(d));
         if (lane == 0) smask[b] = mk;
     }
     __syncthreads();
+    if (DBG && lane == 0) dbg[1] = wall_clock64();
     // ---- phase A: the owner of the junction pixel of this wave's segment start
     if (wave > 0) {
         int n = 0;
@@ -535,10 +548,17 @@ __global__ void __launch_bounds__(256) k_env(const ColDesc* __restrict__ desc, i
         }
         float best = inf;
         int bestu = 0;
-        auto eval_word = [&](int wd) {
-            unsigned long long mk = uni64(smask[wd]);
-            if (!mk) return;
-            const uint4 dv = dp[min(wd * 64 + lane, W - 1)];
+        // A column can only matter if even its smallest value over the chunk's 64 rows (squared distance from the
+        // chunk to the column's nearest seed, from the descriptor) plus its distance to x is within the bound: one
+        // vector test per word (lane = column) leaves the few columns worth a per-row evaluation.
+        const int y0 = c * 64, y63 = y0 + 63;
+        auto eval_word = [&](int wd, const uint4& dv, float bound) {
+            const unsigned long long seeded = uni64(smask[wd]);
+            if (!seeded) return;
+            const float up = (float)(y0 - (int)dv.z), dn = (float)((int)dv.w - y63);  // 2^30 when there is none
+            const float lb = (dv.x | dv.y) ? 0.f : fminf(up, dn);
+            const float dx = (float)(wd * 64 + lane - x);
+            unsigned long long mk = __ballot(lb * lb + dx * dx <= bound) & seeded;
             while (mk) {
                 const int j = __ffsll((long long)mk) - 1;
                 mk &= mk - 1ull;
@@ -552,9 +572,13 @@ __global__ void __launch_bounds__(256) k_env(const ColDesc* __restrict__ desc, i
                 const bool better = val < best || (val == best && u < bestu);
                 best = better ? val : best;
                 bestu = better ? u : bestu;
+                if (DBG) ++n_eval;
             }
         };
         const int wi = x >> 6;
+        // descriptors of the words one step ahead are in flight while a step is evaluated
+        auto load_word = [&](int wd) { return dp[min(min(max(wd, 0), nwords - 1) * 64 + lane, W - 1)]; };
+        uint4 dR = load_word(wi), dL = dR, dRn = load_word(wi + 1), dLn = load_word(wi - 1);
         for (int s = 0;; ++s) {
             const int wr = wi + s, wl = wi - s;
             // values are >= +0, so their bit patterns order like the values
@@ -563,187 +587,286 @@ __global__ void __launch_bounds__(256) k_env(const ColDesc* __restrict__ desc, i
             if (doR && s > 0) { const int d = wr * 64 - x; doR = (float)(d * d) <= mb; }
             if (doL) { const int d = x - (wl * 64 + 63); doL = (float)(d * d) <= mb; }
             if (!doR && !doL) break;
-            if (doR) eval_word(wr);
-            if (doL) eval_word(wl);
+            const uint4 cR = dR, cL = dL;
+            dR = dRn; dL = dLn;
+            dRn = load_word(wr + 2); dLn = load_word(wl - 2);
+            if (doR) eval_word(wr, cR, mb);
+            if (doL) eval_word(wl, cL, mb);
         }
         cj[wave][lane] = bestu;
     }
+    if (DBG && lane == 0) dbg[2] = wall_clock64();
     __syncthreads();
+    if (DBG && lane == 0) dbg[3] = wall_clock64();
     // ---- phase B: the literal run over the columns (cs, ce] on a stack whose bottom is column cs
     const int cs = wave == 0 ? 0 : cj[wave][lane];
     int ce = wave == S - 1 ? W - 1 : cj[wave + 1][lane];
     ce = max(ce, cs);
     const uint4 db = dp[cs];
-    int tv = cs;
+    // top entry t and the entry below it u (a register copy of ring entry cnt - 1, so that a single pop needs no
+    // LDS round trip): column (as float), f, z, column^2
+    float tvf = (float)cs;
     float tf = column_value<true>(((unsigned long long)db.y << 32) | db.x, (int)db.z, (int)db.w, lane, y);
     float tz = -inf;
-    float tvf = (float)tv, tv2 = tvf * tvf, tvx2 = tvf + tvf;
+    float tv2 = tvf * tvf, tvx2 = tvf + tvf;
+    float4 u = make_float4(0.f, 0.f, 0.f, 0.f);
     int cnt = 0;   // entries below the top (indices 0..cnt-1); [base, cnt) in the LDS ring, [0, base) in HBM
     int base = 0;
     float minF = inf;
     const int slot0 = cs + wave;  // segments of a row use disjoint slot ranges
+    EnvEntry* ent = B.ent + r * (size_t)B.eslots + slot0;
     auto evict = [&]() {
-        const int rb = base & (C - 1);
-        const size_t o = (size_t)(slot0 + base) * NR + r;
-        B.ev[o] = r_v[rb][tid]; B.ef[o] = r_f[rb][tid]; B.ez[o] = r_z[rb][tid];
+        const float4 e = ring[base & (C - 1)][tid];
+        ent[base] = EnvEntry{(int)e.x, e.y, e.z};
         ++base;
+        if (DBG) ++n_evict;
     };
     const int qlo = __builtin_amdgcn_readfirstlane(wave_min(cs)) + 1;
     const int qhi = __builtin_amdgcn_readfirstlane(wave_max(ce));
     if (qlo <= qhi) {
         const int wlo = qlo >> 6, whi = qhi >> 6;
-        uint4 dreg = dp[min(wlo * 64 + lane, W - 1)];
         for (int wd = wlo; wd <= whi; ++wd) {
-            const uint4 dnext = dp[min((wd + 1) * 64 + lane, W - 1)];  // in flight during this word
-            unsigned long long mk = uni64(smask[wd]);  // seedless columns are skipped (see k_pass2_l2)
-            if (wd == wlo) mk &= ~0ull << (qlo & 63);
-            if (wd == whi) mk &= ~0ull >> (63 - (qhi & 63));
-            while (mk) {
-                const int j = __ffsll((long long)mk) - 1;
-                mk &= mk - 1ull;
-                const int q = wd * 64 + j;
-                unsigned long long wc;
-                int pc, nc;
-                desc_lane4(dreg, j, wc, pc, nc);
-                const float fq = column_value<true>(wc, pc, nc, lane, y);
-                const bool act = q > cs && q <= ce;
-                const float qf = (float)q;
-                const float q2 = qf * qf;  // rounds like the reference's float(long(q * q))
-                const float hq = fq + q2;
-                const float twoq = qf + qf;
-                float s;
-                while (true) {
-                    // s = ((f[q] + q^2) - f[v] - v^2) / (2q - 2v), left to right in float (imgproc.h:111)
-                    const float N = (hq - tf) - tv2;
-                    s = N / (twoq - tvx2);
-                    const bool pop = act && !(s > tz) && cnt > 0;  // cnt > 0: the bottom (z = -inf) is never popped
-                    if (!__any(pop)) break;
-                    if (pop) {
-                        if (cnt == base) {  // ring empty: one spilled entry comes back (rare)
-                            --base;
-                            const int rb = base & (C - 1);
-                            const size_t o = (size_t)(slot0 + base) * NR + r;
-                            r_v[rb][tid] = B.ev[o]; r_f[rb][tid] = B.ef[o]; r_z[rb][tid] = B.ez[o];
+            {
+                // Lane j holds the descriptor of column 64 wd + j; a column's fields are read with v_readlane.  Loaded and
+                // waited for here, once per 64 columns, and not prefetched across words: a load still pending over the
+                // column loop makes the compiler wait for (nearly) all memory operations at every column, i.e. for the
+                // spill stores, and a descriptor staged in LDS couples every column to the ring traffic through lgkmcnt.
+                const uint4 dcur = dp[min(wd * 64 + lane, W - 1)];
+                asm volatile("; descriptors %0 %1 %2 %3 are complete here, before the column loop" ::"v"(dcur.x), "v"(dcur.y), "v"(dcur.z), "v"(dcur.w));
+                unsigned long long mk = uni64(smask[wd]);  // seedless columns are skipped (see k_pass2_l2)
+                if (wd == wlo) mk &= ~0ull << (qlo & 63);
+                if (wd == whi) mk &= ~0ull >> (63 - (qhi & 63));
+                while (mk) {
+                    const int j = __ffsll((long long)mk) - 1;
+                    mk &= mk - 1ull;
+                    const int q = wd * 64 + j;
+                    uint4 dq;
+                    dq.x = (unsigned)__builtin_amdgcn_readlane((int)dcur.x, j);
+                    dq.y = (unsigned)__builtin_amdgcn_readlane((int)dcur.y, j);
+                    dq.z = (unsigned)__builtin_amdgcn_readlane((int)dcur.z, j);
+                    dq.w = (unsigned)__builtin_amdgcn_readlane((int)dcur.w, j);
+                    float fq = column_value<true>(((unsigned long long)dq.y << 32) | dq.x, (int)dq.z, (int)dq.w, lane, y);
+                    if (DBG && (expm & 4)) fq = (float)((lane * 7 + q * 13) & 1023);  // timing experiment: no pass-1 value
+                    const bool act = q > cs && q <= ce;
+                    const float qf = (float)q;
+                    const float q2 = qf * qf;  // rounds like the reference's float(long(q * q))
+                    const float hq = fq + q2;
+                    const float twoq = qf + qf;
+                    float s;
+                    bool pop;
+                    if (DBG) ++n_cols;
+                    // Test at the bottom: one taken branch per extra pass, none on the way out.  A lane that does not pop
+                    // recomputes the same s in the passes other lanes still need.  (A fully predicated body -- selects
+                    // instead of the branches below -- measured 17 % slower: a lone wave retires a dependent instruction
+                    // every ~8 cycles, so the instruction count of the chain is what matters, not its branches.)
+                    do {
+                        if (DBG) ++n_iter;
+                        // s = ((f[q] + q^2) - f[v] - v^2) / (2q - 2v), left to right in float (imgproc.h:111)
+                        const float N = (hq - tf) - tv2;
+                        s = N / (twoq - tvx2);
+                        if (DBG && (expm & 2)) s = N * __builtin_amdgcn_rcpf(twoq - tvx2);  // timing experiment: no division
+                        pop = act && !(s > tz) && cnt > 0;  // cnt > 0: the bottom (z = -inf) is never popped
+                        if (DBG && (expm & 1)) pop = false;  // timing experiment: no pops
+                        if (pop) {
+                            tvf = u.x; tf = u.y; tz = u.z; tv2 = u.w; tvx2 = u.x + u.x;
+                            --cnt;
+                            if (cnt > 0) {
+                                if (__builtin_expect(cnt == base, 0)) {  // ring empty: up to four spilled entries come back together
+                                    EnvEntry en[4];
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) en[e] = ent[max(base - 1 - e, 0)];
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) {  // all four are written (the ring is empty; entries below 0 land in free slots): no load stays pending
+                                        const float vf = (float)en[e].v;
+                                        ring[(base - 1 - e) & (C - 1)][tid] = make_float4(vf, en[e].f, en[e].z, vf * vf);
+                                    }
+                                    base = max(base - 4, 0);
+                                    if (DBG) ++n_refill;
+                                }
+                                u = ring[(cnt - 1) & (C - 1)][tid];  // needed at the next pop at the earliest
+                            }
                         }
-                        --cnt;
-                        const int rr = cnt & (C - 1);
-                        tv = r_v[rr][tid]; tf = r_f[rr][tid]; tz = r_z[rr][tid];
-                        tvf = (float)tv; tv2 = tvf * tvf; tvx2 = tvf + tvf;
+                    } while (__builtin_amdgcn_ballot_w64(pop) != 0ull);
+                    if (act) {
+                        if (cnt == 0) minF = s < minF ? s : minF;  // a test against the bottom entry
+                        if (__builtin_expect(cnt - base == C, 0)) evict();
+                        u = make_float4(tvf, tf, tz, tv2);
+                        ring[cnt & (C - 1)][tid] = u;
+                        ++cnt;
+                        tvf = qf; tf = fq; tz = s; tv2 = q2; tvx2 = twoq;
                     }
                 }
-                if (act) {
-                    if (cnt == 0) minF = s < minF ? s : minF;  // a test against the bottom entry
-                    if (cnt - base == C) evict();
-                    const int rr = cnt & (C - 1);
-                    r_v[rr][tid] = tv; r_f[rr][tid] = tf; r_z[rr][tid] = tz;
-                    ++cnt;
-                    tv = q; tf = fq; tz = s; tv2 = q2; tvx2 = twoq;
-                }
             }
-            dreg = dnext;
         }
     }
+    if (DBG && lane == 0) dbg[4] = wall_clock64();
     // the top joins the entries; everything still in the ring goes to HBM
     if (cnt - base == C) evict();
-    {
-        const int rr = cnt & (C - 1);
-        r_v[rr][tid] = tv; r_f[rr][tid] = tf; r_z[rr][tid] = tz;
-        ++cnt;
-    }
+    ring[cnt & (C - 1)][tid] = make_float4(tvf, tf, tz, tv2);
+    ++cnt;
 #pragma unroll
     for (int e = 0; e < C; ++e) {
         const int i = base + e;
         if (i < cnt) {
-            const int rb = i & (C - 1);
-            const size_t o = (size_t)(slot0 + i) * NR + r;
-            B.ev[o] = r_v[rb][tid]; B.ef[o] = r_f[rb][tid]; B.ez[o] = r_z[rb][tid];
+            const float4 en = ring[i & (C - 1)][tid];
+            ent[i] = EnvEntry{(int)en.x, en.y, en.z};
         }
     }
     const size_t to = (size_t)wave * NR + r;
     B.tcnt[to] = cnt; B.tminf[to] = minF; B.tslot[to] = slot0;
+    if (DBG && lane == 0) {
+        dbg[5] = wall_clock64();
+        dbg[6] = n_cols; dbg[7] = n_iter; dbg[8] = n_evict; dbg[9] = n_refill;
+        dbg[10] = qhi - qlo + 1; dbg[15] = n_eval;
+        if (wave == 1) dbg[11] = clock64() - sc0;  // shader clocks of this wave's life (k_addend uses wave 0's slot 11)
+    }
 }
 
-// Junction check + one walk over the concatenated stack of a row (lane = row).
-template <int KL>
-__global__ void __launch_bounds__(256) k_addend(int W, int S, int part_w, K2Buf B, int force_mod) {
-    __shared__ unsigned l_pk[KL][256];  // the last KL owner entries of each row
-    __shared__ float l_b[KL][256];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const long chunk = (long)blockIdx.x * 4 + wave;
+// Junction check + one walk over the concatenated stack of a row (lane = row, one wave per block).  The stack of a
+// row is the stacks of its segments back to back, without the bottom entries of segments 1.. (they repeat the
+// previous segment's top).  Every lane streams through its own row; the entries of a batch are staged in LDS so
+// that one compact loop body serves every entry; the owner entries collect in an LDS ring and go to HBM in
+// bursts, so that the loads of the walk do not queue behind stores.
+template <int KL, bool DBG>
+__global__ void __launch_bounds__(64) k_addend(int W, int S, int part_w, K2Buf B, int force_mod) {
+    constexpr int NB = 16;                // entries per batch
+    __shared__ unsigned l_pk[KL][64];     // the last KL owner entries of each row
+    __shared__ float l_b[KL][64];
+    __shared__ int e_v[NB][64];           // the batch being walked
+    __shared__ float e_f[NB][64];
+    __shared__ float e_z[NB][64];
+    const int lane = threadIdx.x;
+    const long chunk = blockIdx.x;
     const size_t NR = (size_t)B.NR;
-    if ((size_t)chunk * 64 >= NR) return;
     const size_t r = (size_t)chunk * 64 + lane;
-    int pend_v = 0, pend_st = 0, last_st = -1, lc = 0, pi1 = 0, pi2 = 0, pi3 = 0;
-    float pend_f = 0.f, pend_z = 0.f;
-    bool have = false, ok = true;
+    OwnEntry* own = B.own + r * (size_t)B.lslots;
+    const EnvEntry* ent = B.ent + r * (size_t)B.eslots;
+    long long* dbg = DBG ? B.dbg + ((size_t)chunk * kSegMax) * 16 : nullptr;
+    long long n_batches = 0;
+    if (DBG && lane == 0) dbg[11] = wall_clock64();
+    // Segment table of the row: stream index i lies in segment w for i in [o_w, o_{w+1}), at slot i + K_w.  The
+    // junction checks: every test against a segment's bottom column must also push on the real stack, where that
+    // column is the previous segment's top (min s over those tests > z of that top).
+    int o[kSegMax + 1], K[kSegMax];
+    bool ok = true;
+    {
+        int n_prev = B.tcnt[r], s_prev = B.tslot[r];
+        o[0] = 0; o[1] = n_prev; K[0] = s_prev;
+#pragma unroll
+        for (int w = 1; w < kSegMax; ++w) {
+            o[w + 1] = o[w]; K[w] = 0;
+            if (w < S) {
+                const int n = B.tcnt[(size_t)w * NR + r], s0 = B.tslot[(size_t)w * NR + r];
+                const EnvEntry top = ent[s_prev + n_prev - 1];
+                ok = ok && B.tminf[(size_t)w * NR + r] > top.z && top.v == s0 - w;
+                o[w + 1] = o[w] + n - 1; K[w] = s0 - o[w] + 1;
+                n_prev = n; s_prev = s0;
+            }
+        }
+    }
+    const int total = o[kSegMax];
+    auto slot_of = [&](int i) {
+        int k = K[0];
+#pragma unroll
+        for (int w = 1; w < kSegMax; ++w) k = i >= o[w] ? K[w] : k;
+        return i + k;
+    };
+    int pend_v = 0, pend_st = -1, last_st = -1, lc = 0, flushed = 0, pi1 = 0, pi2 = 0, pi3 = 0;
+    int optr = 0;  // owner list index whose first pixel is <= the column looked up last (columns only grow)
+    float pend_f = 0.f;
+    auto list_pk = [&](int i) -> unsigned {
+        if (i >= lc - KL) return l_pk[i & (KL - 1)][lane];
+        const unsigned a0 = own[i].pk;  // older than the LDS window (rare): from the list in HBM, consumed in place
+        unsigned v;
+        asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "v"(a0));
+        return v;
+    };
+    auto list_b = [&](int i) -> float {
+        if (i >= lc - KL) return l_b[i & (KL - 1)][lane];
+        const float a0 = own[i].b;
+        float v;
+        asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "v"(a0));
+        return v;
+    };
     // The pending entry owns the pixels [pend_st, st_next) if that range is not empty (owner of q = the last
     // entry with z < q, imgproc.h:124).  Addend: f[v] if it takes over at or before its own column, else the
-    // value the reference reads back at v: g[v] = addend_o + (v - v_o)^2 with o the owner of pixel v.
+    // value the reference reads back at v: g[v] = addend_o + (v - v_o)^2 with o the owner of pixel v.  The
+    // columns of successive entries grow, so o is found with a pointer that only moves forward.
     auto finalize = [&](int st_next) {
-        if (pend_st < st_next && pend_st > last_st) {
-            float b = pend_f;
-            if (pend_st > pend_v) {
-                int o = lc - 1;
-                unsigned pk;
-                float bo;
-                while (true) {
-                    if (o >= lc - KL) {
-                        pk = l_pk[o & (KL - 1)][tid]; bo = l_b[o & (KL - 1)][tid];
-                    } else {  // older than the LDS window (rare): from the list in HBM, consumed in place
-                        const unsigned a0 = B.lpk[(size_t)o * NR + r];
-                        const float a1 = B.lb[(size_t)o * NR + r];
-                        asm volatile("v_mov_b32 %0, %1" : "=v"(pk) : "v"(a0));
-                        asm volatile("v_mov_b32 %0, %1" : "=v"(bo) : "v"(a1));
+        const bool owns = pend_st >= 0 && pend_st < st_next && pend_st > last_st;
+        const bool quirk = owns && pend_st > pend_v;
+        float b = pend_f;
+        if (__builtin_amdgcn_ballot_w64(quirk) != 0ull) {
+            if (quirk) {
+                // last list entry whose first pixel is <= pend_v, at or after optr: two steps forward (rows along a scene
+                // line need one per entry), else gallop back from the tail (the owner is a few entries back) and bisect
+                if (optr + 1 < lc && (int)(list_pk(optr + 1) >> 16) <= pend_v) {
+                    ++optr;
+                    if (optr + 1 < lc && (int)(list_pk(optr + 1) >> 16) <= pend_v) {
+                        ++optr;
+                        if (optr + 1 < lc && (int)(list_pk(optr + 1) >> 16) <= pend_v) {
+                            int hi = lc - 1, lo = hi, step = 1;
+                            while (lo > optr && (int)(list_pk(lo) >> 16) > pend_v) { hi = lo - 1; lo = max(optr, lo - step); step <<= 1; }
+                            while (lo < hi) {
+                                const int mid = (lo + hi + 1) >> 1;
+                                if ((int)(list_pk(mid) >> 16) <= pend_v) lo = mid; else hi = mid - 1;
+                            }
+                            optr = lo;
+                        }
                     }
-                    if ((int)(pk >> 16) <= pend_v || o == 0) break;
-                    --o;
                 }
+                const unsigned pk = list_pk(optr);
                 const float dv = (float)(pend_v - (int)(pk & 0xffffu));  // dv * dv rounds like float(long(dv * dv))
-                b = bo + dv * dv;
+                b = list_b(optr) + dv * dv;
             }
-            const unsigned npk = ((unsigned)pend_st << 16) | (unsigned)pend_v;
-            l_pk[lc & (KL - 1)][tid] = npk; l_b[lc & (KL - 1)][tid] = b;
-            B.lpk[(size_t)lc * NR + r] = npk; B.lb[(size_t)lc * NR + r] = b;
-            if (pend_st <= part_w) pi1 = lc;
-            if (pend_st <= 2 * part_w) pi2 = lc;
-            if (pend_st <= 3 * part_w) pi3 = lc;
+        }
+        if (owns) {
+            l_pk[lc & (KL - 1)][lane] = ((unsigned)pend_st << 16) | (unsigned)pend_v;
+            l_b[lc & (KL - 1)][lane] = b;
+            pi1 = pend_st <= part_w ? lc : pi1;
+            pi2 = pend_st <= 2 * part_w ? lc : pi2;
+            pi3 = pend_st <= 3 * part_w ? lc : pi3;
             last_st = pend_st;
             ++lc;
         }
     };
-    for (int w = 0; w < S; ++w) {
-        const size_t to = (size_t)w * NR + r;
-        const int n = B.tcnt[to], slot0 = B.tslot[to];
-        const float mf = B.tminf[to];
-        // every test against this segment's bottom column must also push on the real stack, where that column
-        // is the previous segment's top with z = pend_z
-        if (w > 0) ok = ok && mf > pend_z && pend_v == slot0 - w;
-        const int nmax = __builtin_amdgcn_readfirstlane(wave_max(n));
-        for (int e0 = w ? 1 : 0; e0 < nmax; e0 += 8) {  // entry 0 of a later segment repeats the previous top
-            int vv[8];
-            float ff[8], zz[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const size_t o = (size_t)(slot0 + min(e0 + u, n - 1)) * NR + r;
-                vv[u] = B.ev[o]; ff[u] = B.ef[o]; zz[u] = B.ez[o];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                if (e0 + u < n) {
-                    const float z = zz[u];
-                    // first pixel above z: the entry takes over there (while (z[k+1] < q) ++k)
-                    const int st = z < 0.f ? 0 : (!(z < (float)W) ? W : (int)floorf(z) + 1);
-                    if (have) finalize(st);
-                    pend_v = vv[u]; pend_f = ff[u]; pend_z = z; pend_st = st; have = true;
-                }
-            }
+    auto flush = [&]() {  // ring -> HBM: all lanes together, in list order
+        const int fmax = __builtin_amdgcn_readfirstlane(wave_max(lc - flushed));
+        for (int e = 0; e < fmax; ++e) {
+            const int i = flushed + e;
+            if (i < lc) own[i] = OwnEntry{l_pk[i & (KL - 1)][lane], l_b[i & (KL - 1)][lane]};
         }
+        flushed = lc;
+    };
+    const int tmax = __builtin_amdgcn_readfirstlane(wave_max(total));
+    EnvEntry nxt[NB];
+#pragma unroll
+    for (int u = 0; u < NB; ++u) nxt[u] = ent[slot_of(min(u, total - 1))];
+    for (int i0 = 0; i0 < tmax; i0 += NB) {
+        if (DBG) ++n_batches;
+#pragma unroll
+        for (int u = 0; u < NB; ++u) { e_v[u][lane] = nxt[u].v; e_f[u][lane] = nxt[u].f; e_z[u][lane] = nxt[u].z; }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) nxt[u] = ent[slot_of(min(i0 + NB + u, total - 1))];  // in flight during this batch
+        const int un = min(NB, tmax - i0);
+#pragma unroll 1
+        for (int u = 0; u < un; ++u) {
+            const bool valid = i0 + u < total;
+            const float z = e_z[u][lane];
+            // first pixel above z: the entry takes over there (while (z[k+1] < q) ++k)
+            const int st = z < 0.f ? 0 : (!(z < (float)W) ? W : (int)floorf(z) + 1);
+            finalize(valid ? st : -1);  // -1: nothing is finalised (pend_st >= 0 > -1)
+            if (valid) { pend_v = e_v[u][lane]; pend_f = e_f[u][lane]; pend_st = st; }
+        }
+        if (__builtin_amdgcn_ballot_w64(lc - flushed >= KL / 2) != 0ull) flush();  // a batch adds at most NB < KL / 2
     }
-    if (have) finalize(W);
+    finalize(W);
+    flush();
     B.lcount[r] = lc;
     B.partidx[r] = pi1; B.partidx[NR + r] = pi2; B.partidx[2 * NR + r] = pi3;
     const bool forced = force_mod > 0 && chunk % force_mod == 0;  // test hook: exercise the redo path
-    if ((__any(!ok) || forced) && lane == 0) B.flags[chunk] = 1;
+    if ((__builtin_amdgcn_ballot_w64(!ok) != 0ull || forced) && lane == 0) B.flags[chunk] = 1;
+    if (DBG && lane == 0) { dbg[12] = wall_clock64(); dbg[13] = n_batches; dbg[14] = __builtin_amdgcn_readfirstlane(wave_max(lc)); }
 }
 
 // Pure fill (imgproc.h:122-128) from the owner list; wave p of a block fills the pixels
@@ -764,6 +887,7 @@ __global__ void __launch_bounds__(256) k_fill(float* __restrict__ vol, int W, in
     if (qcur >= qend) return;
     int idx = p == 0 ? 0 : B.partidx[(size_t)(p - 1) * NR + r];
     const int lc = B.lcount[r];
+    const OwnEntry* own = B.own + r * (size_t)B.lslots;
     const auto rs = __builtin_amdgcn_make_buffer_rsrc(vol + (size_t)k * W * H, 0, (unsigned)((size_t)W * H * 4), 0x00020000);
     const unsigned vrow = y < H ? (unsigned)y * 4u : 0x80000000u;  // rows past the image: dropped stores
     const int colB = H * 4;
@@ -773,8 +897,8 @@ __global__ void __launch_bounds__(256) k_fill(float* __restrict__ vol, int W, in
         float bb[RE];
 #pragma unroll
         for (int e = 0; e < RE; ++e) {
-            const size_t o = (size_t)min(idx + e, lc - 1) * NR + r;
-            pk[e] = B.lpk[o]; bb[e] = B.lb[o];
+            const OwnEntry oe = own[min(idx + e, lc - 1)];
+            pk[e] = oe.pk; bb[e] = oe.b;
         }
 #pragma unroll
         for (int e = 0; e < RE; ++e) {
@@ -1174,7 +1298,12 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after) {
     static const bool env_legacy = getenv("FDCM_K2_LEGACY") != nullptr;            // one-wave-per-chunk kernel only
     static const int env_segments = getenv("FDCM_K2_SEGMENTS") ? atoi(getenv("FDCM_K2_SEGMENTS")) : 0;
     static const int env_force_redo = getenv("FDCM_K2_FORCE_REDO") ? atoi(getenv("FDCM_K2_FORCE_REDO")) : 0;
-    const bool segmented = fm->distance != FDCM_L1 && !env_legacy;
+    static const bool env_debug = getenv("FDCM_K2_DEBUG") != nullptr;  // per-wave clock stamps, printed after the sweep
+    static const int env_experiment = getenv("FDCM_K2_EXPERIMENT") ? atoi(getenv("FDCM_K2_EXPERIMENT")) : 0;  // debug kernels only
+    // The segmented sweep wins where the one-wave-per-chunk kernel cannot fill the chip (config 2: 480 chunks, 0.54 vs
+    // 0.65 ms); on large volumes both are bound by the same per-column chain and the fused kernel has less overhead
+    // (config 3: 1920 chunks, 1.79 vs 2.08 ms).  FDCM_K2_SEGMENTS forces the segmented path at any size.
+    const bool segmented = fm->distance != FDCM_L1 && !env_legacy && (nchunks <= 1024 || env_segments > 0);
     int R = 64;                            // rows per wave of the one-wave-per-chunk L2 sweep: keep >= 2048 waves in flight
     if (!segmented) {
         while (R > 16 && nchunks * (64 / R) < 2048) R >>= 1;
@@ -1194,17 +1323,17 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after) {
         const size_t NRr = (size_t)nchunks * 64, slots = (size_t)W + kSegMax + 2, lslots = (size_t)W + 2;
         size_t off = 0;
         auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
-        const size_t o_ev = take(slots * NRr * 4), o_ef = take(slots * NRr * 4), o_ez = take(slots * NRr * 4);
-        const size_t o_lpk = take(lslots * NRr * 4), o_lb = take(lslots * NRr * 4);
+        const size_t o_ent = take(slots * NRr * sizeof(EnvEntry)), o_own = take(lslots * NRr * sizeof(OwnEntry));
         const size_t o_tc = take(kSegMax * NRr * 4), o_tm = take(kSegMax * NRr * 4), o_ts = take(kSegMax * NRr * 4);
         const size_t o_lc = take(NRr * 4), o_pi = take(3 * NRr * 4), o_fl = take((size_t)nchunks * 4);
+        const size_t o_dbg = take(env_debug ? (size_t)nchunks * kSegMax * 16 * 8 : 0);
         fm->stack.reserve(off);
         char* sb = (char*)fm->stack.p;
-        kb.ev = (int*)(sb + o_ev); kb.ef = (float*)(sb + o_ef); kb.ez = (float*)(sb + o_ez);
-        kb.lpk = (unsigned*)(sb + o_lpk); kb.lb = (float*)(sb + o_lb);
+        kb.ent = (EnvEntry*)(sb + o_ent); kb.own = (OwnEntry*)(sb + o_own);
         kb.tcnt = (int*)(sb + o_tc); kb.tminf = (float*)(sb + o_tm); kb.tslot = (int*)(sb + o_ts);
         kb.lcount = (int*)(sb + o_lc); kb.partidx = (int*)(sb + o_pi); kb.flags = (int*)(sb + o_fl);
-        kb.NR = (long)NRr;
+        kb.dbg = env_debug ? (long long*)(sb + o_dbg) : nullptr;
+        kb.NR = (long)NRr; kb.eslots = (int)slots; kb.lslots = (int)lslots;
     }
     // ---- plan upload: one pinned blob, one async copy
     auto align16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
@@ -1255,18 +1384,70 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after) {
             }
         } else {
             // the one-wave-per-chunk kernel uses the entry arrays as its (v, f, z) scratch: [W][nwaves * R] each
-            int* sv = kb.ev;
-            float* sf = kb.ef;
-            float* sz = kb.ez;
+            int* sv = (int*)kb.ent;
+            float* sf = (float*)(sv + (size_t)W * nwaves * R);
+            float* sz = sf + (size_t)W * nwaves * R;
             const int* gate = nullptr;
 #define FDCM_K2(RR, CC, SS, PP) hipLaunchKernelGGL((k_pass2_l2<RR, CC, SS, PP>), dim3(wblocks), dim3(256), 0, st, d_desc, vol, W, H, HW64, nwaves, sv, sf, sz, gate)
             if (segmented) {
-                hipLaunchKernelGGL(k_env<16>, dim3((unsigned)nchunks), dim3(64 * S), 0, st, d_desc, W, H, HW64, S, kb);
-                hipLaunchKernelGGL(k_addend<8>, dim3((unsigned)((nchunks + 3) / 4)), dim3(256), 0, st, W, S, part_w, kb, env_force_redo);
+                // up to 4 segments: 256-thread blocks, 16-entry ring, two words of descriptors staged at a time;
+                // up to 8: 512-thread blocks with an 8-entry ring and one word (both ~75 KB of LDS: two blocks per CU)
+#define FDCM_ENV(CC, NN, GG, DD) hipLaunchKernelGGL((k_env<CC, NN, GG, DD>), dim3((unsigned)nchunks), dim3(64 * S), 0, st, d_desc, W, H, HW64, S, kb, env_experiment)
+                if (S <= 4) { if (env_debug) FDCM_ENV(16, 256, 2, true); else FDCM_ENV(16, 256, 2, false); }
+                else { if (env_debug) FDCM_ENV(8, 512, 1, true); else FDCM_ENV(8, 512, 1, false); }
+#undef FDCM_ENV
+                if (env_debug) hipLaunchKernelGGL((k_addend<64, true>), dim3((unsigned)nchunks), dim3(64), 0, st, W, S, part_w, kb, env_force_redo);
+                else hipLaunchKernelGGL((k_addend<64, false>), dim3((unsigned)nchunks), dim3(64), 0, st, W, S, part_w, kb, env_force_redo);
                 hipLaunchKernelGGL(k_fill<16>, dim3((unsigned)nchunks), dim3(256), 0, st, vol, W, H, HW64, part_w, kb);
                 // chunks whose junction check failed are redone literally, one wave per chunk (all others exit at once)
                 gate = kb.flags;
                 FDCM_K2(64, 8, 4, false);
+                if (env_debug) {  // diagnostic: per-wave phase times (100 MHz clock) and loop counters
+                    FDCM_HIP(hipStreamSynchronize(st));
+                    std::vector<long long> d((size_t)nchunks * kSegMax * 16);
+                    FDCM_HIP(hipMemcpy(d.data(), kb.dbg, d.size() * 8, hipMemcpyDeviceToHost));
+                    std::vector<int> fl((size_t)nchunks);
+                    FDCM_HIP(hipMemcpy(fl.data(), kb.flags, fl.size() * 4, hipMemcpyDeviceToHost));
+                    double sum[6] = {0, 0, 0, 0, 0, 0}, mx[6] = {0, 0, 0, 0, 0, 0}, cnt[5] = {0, 0, 0, 0, 0}, cmx[5] = {0, 0, 0, 0, 0};
+                    double ad_sum = 0, ad_max = 0, ab_sum = 0, ab_max = 0, lc_max = 0, ev_sum = 0;
+                    std::vector<double> v_loop, v_cols, v_tot, v_ad;
+                    long nw = 0, flagged = 0;
+                    for (long ch = 0; ch < nchunks; ++ch) {
+                        flagged += fl[ch];
+                        for (int w = 0; w < S; ++w, ++nw) {
+                            const long long* e = &d[((size_t)ch * kSegMax + w) * 16];
+                            const double ph[6] = {(e[1] - e[0]) / 100.0, (e[2] - e[1]) / 100.0, (e[3] - e[2]) / 100.0,
+                                                  (e[4] - e[3]) / 100.0, (e[5] - e[4]) / 100.0, (e[5] - e[0]) / 100.0};
+                            for (int i = 0; i < 6; ++i) { sum[i] += ph[i]; mx[i] = std::max(mx[i], ph[i]); }
+                            for (int i = 0; i < 5; ++i) { cnt[i] += (double)e[6 + i]; cmx[i] = std::max(cmx[i], (double)e[6 + i]); }
+                            v_loop.push_back(ph[3]); v_cols.push_back((double)e[6]); v_tot.push_back(ph[5]); ev_sum += (double)e[15];
+                        }
+                        const long long* e = &d[(size_t)ch * kSegMax * 16];
+                        const double t = (e[12] - e[11]) / 100.0;
+                        v_ad.push_back(t);
+                        ad_sum += t; ad_max = std::max(ad_max, t); ab_sum += (double)e[13]; ab_max = std::max(ab_max, (double)e[13]);
+                        lc_max = std::max(lc_max, (double)e[14]);
+                    }
+                    fprintf(stderr, "[k2 debug] S=%d waves=%ld flagged chunks=%ld | k_env us avg/max: mask %.1f/%.1f scanA %.1f/%.1f sync %.1f/%.1f "
+                            "loopB %.1f/%.1f flush %.1f/%.1f total %.1f/%.1f | per wave avg/max: cols %.0f/%.0f iters %.0f/%.0f evict %.0f/%.0f "
+                            "refill %.0f/%.0f range %.0f/%.0f | k_addend us %.1f/%.1f batches %.1f/%.0f max owners %.0f\n",
+                            S, nw, flagged, sum[0] / nw, mx[0], sum[1] / nw, mx[1], sum[2] / nw, mx[2], sum[3] / nw, mx[3], sum[4] / nw, mx[4],
+                            sum[5] / nw, mx[5], cnt[0] / nw, cmx[0], cnt[1] / nw, cmx[1], cnt[2] / nw, cmx[2], cnt[3] / nw, cmx[3],
+                            cnt[4] / nw, cmx[4], ad_sum / nchunks, ad_max, ab_sum / nchunks, ab_max, lc_max);
+                    {
+                        double mhz = 0; long nm = 0;
+                        if (S > 1) for (long ch = 0; ch < nchunks; ++ch) {
+                            const long long* e = &d[((size_t)ch * kSegMax + 1) * 16];
+                            if (e[5] > e[0]) { mhz += (double)e[11] / ((e[5] - e[0]) / 100.0); ++nm; }
+                        }
+                        fprintf(stderr, "[k2 debug] shader clock during k_env: %.0f MHz (clock64 / wall_clock64 over %ld waves)\n", nm ? mhz / nm : 0.0, nm);
+                    }
+                    auto pct = [](std::vector<double>& v, double q) { std::sort(v.begin(), v.end()); return v[(size_t)(q * (v.size() - 1))]; };
+                    fprintf(stderr, "[k2 debug] p50/p90/p99: loopB us %.1f/%.1f/%.1f cols %.0f/%.0f/%.0f wave total us %.1f/%.1f/%.1f addend us %.1f/%.1f/%.1f; scan evals per junction %.0f\n",
+                            pct(v_loop, .5), pct(v_loop, .9), pct(v_loop, .99), pct(v_cols, .5), pct(v_cols, .9), pct(v_cols, .99),
+                            pct(v_tot, .5), pct(v_tot, .9), pct(v_tot, .99), pct(v_ad, .5), pct(v_ad, .9), pct(v_ad, .99),
+                            ev_sum / std::max(1.0, (double)nchunks * (S - 1)));
+                }
             } else {
                 // LDS per block = (3 C + 3 SG) * 4R * 4 B + 4 KiB; a CU holds 160 KiB.  Small grids get the long
                 // ring (fewer HBM round trips in the fill), large grids the short one (all waves resident).

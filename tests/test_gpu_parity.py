@@ -505,16 +505,23 @@ def test_search_many_templates_generic_work_list(amd):
     assert assert_matches_close(got, want, "1531 templates"), "not bit-identical"
 
 
-def test_randomised_cases(amd):
-    """80 random (scene, depth, distance, padding, coefficient, optimiser, template set) cases: volume and
-    match list bit for bit (tools/fuzz_parity.py; larger runs by hand: 3300 cases identical this round)."""
+@pytest.mark.parametrize("env,cases,seed", [({}, 80, 11),
+                                            ({"FDCM_K2_SEGMENTS": "8", "FDCM_K2_FORCE_REDO": "5"}, 40, 12),
+                                            ({"FDCM_K2_SEGMENTS": "3"}, 40, 13),
+                                            ({"FDCM_K2_LEGACY": "1"}, 40, 14)],
+                         ids=["default", "8-segments+forced-redo", "3-segments", "one-wave-per-chunk"])
+def test_randomised_cases(amd, env, cases, seed):
+    """Random (scene, depth, distance, padding, coefficient, optimiser, template set) cases: volume and match list
+    bit for bit (tools/fuzz_parity.py).  The variants force the paths of the L2 sweep that the default sizes do not
+    take: eight segments per row with every fifth chunk sent through the redo path (a failed junction check), three
+    segments, and the one-wave-per-chunk kernel alone."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "80", "11"], capture_output=True,
-                         text=True, timeout=600)
-    assert out.returncode == 0 and "80 random cases identical" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), str(cases), str(seed)],
+                         capture_output=True, text=True, timeout=600, env={**os.environ, **env})
+    assert out.returncode == 0 and f"{cases} random cases identical" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
 
 def test_frame_pipeline_reports_a_failed_frame_and_keeps_going(amd):
