@@ -176,6 +176,8 @@ class ShardedPipeline:
             self.gatherer = FrameGatherer(capacity_records, device, group=group, depth=slots + 2)
         self.pending = []
         self.submitted = 0
+        # per slot: event recorded (on torch's stream) behind the collective that reads the slot's record buffer
+        self.sent = [None] * slots
 
     @classmethod
     def create(cls, searcher, n_scene_lines, depth, coeff, padding, distance, max_tmpl_lines, max_scene_lines,
@@ -189,7 +191,14 @@ class ShardedPipeline:
 
     def submit(self, scene_records):
         """Queue one frame (at most `slots` may be uncollected); scene_records: (N, 4) float32."""
-        buf = self.bufs[self.submitted % self.slots] if self.bufs is not None else None
+        slot = self.submitted % self.slots
+        buf = self.bufs[slot] if self.bufs is not None else None
+        if self.sent[slot] is not None:
+            # The slot's record buffer is the send buffer of the previous frame's gather, which RCCL runs on torch's
+            # stream; the library writes the buffer from the slot's own (non-blocking) stream.  On ranks other than
+            # the destination nothing else orders the two, so the next frame waits for that send here.
+            self.sent[slot].synchronize()
+            self.sent[slot] = None
         t = self.pipe.submit(scene_records, buf.data_ptr() if buf is not None else None, prepared=True)
         assert t == self.submitted
         self.submitted += 1
@@ -204,7 +213,12 @@ class ShardedPipeline:
         res = self.pipe.wait(t)
         if buf is None:
             return res
-        return self.gatherer.gather(buf, int(res))
+        out = self.gatherer.gather(buf, int(res))
+        if self.device.type == "cuda":
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            self.sent[t % self.slots] = ev
+        return out
 
     def close(self):
         while self.pending:

@@ -1,18 +1,36 @@
 #!/bin/bash
 # Collect the round's judged measurements on the GPU box into gpurun_out/<tag>/ (copy into profiles/ afterwards).
-# usage (inside gpurun): bash tools/collect_profiles.sh r01
-R=/root/repo
+# usage (inside gpurun): bash tools/collect_profiles.sh r02
+# The program goes directly after `--` (no env / bash -c hop under rocprofv3); the queue count bench.py asks for is
+# exported here because under rocprofv3 the GPU is initialised before python starts.
+R=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$R/gpurun_out/${1:-prof}
 mkdir -p $OUT
+export GPU_MAX_HW_QUEUES=8
+export TMPDIR=/tmp
+cd /tmp
 python3 $R/bench.py > $OUT/bench.json 2> $OUT/bench.err
-cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -o ks -- python3 $R/bench.py --cpu-sample 0 > /dev/null 2>&1
-cp $(find /tmp/ks -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks1 -o ks1 -- python3 $R/bench.py --cpu-sample 0 --frames 1 --single-frames 0 > /dev/null 2>&1
-cp $(find /tmp/ks1 -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_frames1.csv
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pf -o pf --output-format csv -- python3 $R/bench.py --frames 1 --steps 5 --warmup 2 --cpu-sample 0 --single-frames 0 > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/pw -o pw --output-format csv -- python3 $R/bench.py --frames 1 --steps 5 --warmup 2 --cpu-sample 0 --single-frames 0 > /dev/null 2>&1
-python3 $R/tools/pmc_traffic.py /tmp/pf /tmp/pw $OUT/pmc_traffic.json > /dev/null
-cut -c1-400 $OUT/bench.json
-head -3 $OUT/kernel_stats.csv | cut -c1-120
-head -3 $OUT/kernel_stats_frames1.csv | cut -c1-120
+python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_cmd.json 2>> $OUT/bench.err
+stats() {  # stats <name> <program args...>: rocprofv3 --kernel-trace --stats summary of a command
+  local name=$1; shift
+  rm -rf /tmp/ks_$name
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_$name -o ks -- "$@" > /dev/null 2>&1
+  cp "$(find /tmp/ks_$name -name '*kernel_stats.csv' | head -1)" $OUT/${name}_kernel_stats.csv
+}
+pmc() {  # pmc <name> <program args...>: HBM bytes per kernel launch (two passes)
+  local name=$1; shift
+  rm -rf /tmp/pf_$name /tmp/pw_$name
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pf_$name -o pf --output-format csv -- "$@" > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/pw_$name -o pw --output-format csv -- "$@" > /dev/null 2>&1
+  python3 $R/tools/pmc_traffic.py /tmp/pf_$name /tmp/pw_$name $OUT/pmc_traffic_$name.json "$*" > /dev/null
+}
+stats bench_config2p python3 $R/bench.py --cpu-sample 0
+stats bench_config2p_frames1 python3 $R/bench.py --cpu-sample 0 --frames 1 --single-frames 0
+pmc config2p python3 $R/bench.py --frames 1 --steps 5 --warmup 2 --cpu-sample 0 --single-frames 0
+for cfg in 3 5; do
+  python3 $R/tools/run_config.py --config $cfg --check none --reps 7 --search --templates 200 > $OUT/run_config$cfg.json 2>> $OUT/bench.err
+  stats config$cfg python3 $R/tools/run_config.py --config $cfg --check none --reps 7 --search --templates 200
+  pmc config$cfg python3 $R/tools/run_config.py --config $cfg --check none --reps 3
+done
+cut -c1-300 $OUT/bench.json
+for f in $OUT/*_kernel_stats.csv; do echo $f; head -4 $f | cut -c1-110; done

@@ -7,7 +7,7 @@ FETCH_SIZE reports exactly half of the bytes of a wide coalesced streaming read,
 (`fetch_corrected`); WRITE_SIZE is exact.  For the gather-dominated k_search the doubling is not
 calibrated and the raw value is kept beside it.
 
-usage: pmc_traffic.py <fetch_dir> <write_dir> <out.json>
+usage: pmc_traffic.py <fetch_dir> <write_dir> <out.json> [command line that was profiled]
 """
 import collections
 import csv
@@ -34,8 +34,13 @@ def main():
         fr, wr = fetch.get(k, 0.0) * 1024, write.get(k, 0.0) * 1024
         out[k] = {"fetch_raw_bytes": fr, "fetch_corrected_bytes": 2 * fr, "write_bytes": wr,
                   "hbm_bytes_per_launch": 2 * fr + wr}
-    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py "
-                         "--steps 5 --warmup 2 --cpu-sample 0", "kernels": out}, open(sys.argv[3], "w"), indent=1)
+    import hashlib
+    import os
+    so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "openfdcm_amd", "libfdcm_hip.so")
+    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- " + (sys.argv[4] if len(sys.argv) > 4 else
+                         "python3 bench.py --frames 1 --steps 5 --warmup 2 --cpu-sample 0 --single-frames 0"),
+               "so_sha256_16": hashlib.sha256(open(so, "rb").read()).hexdigest()[:16],
+               "kernels": out}, open(sys.argv[3], "w"), indent=1)
     print(json.dumps(out, indent=1))
 
 
