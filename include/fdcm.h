@@ -138,6 +138,34 @@ int fdcm_search_device(const fdcm_featuremap* fm, const fdcm_templates* template
 int fdcm_search_last_timing(const fdcm_featuremap* fm, fdcm_search_timing* t);
 void fdcm_matches_free(fdcm_match* m); /* match arrays are pinned host buffers from a pool inside the library */
 
+/* ---- template shards over several GPUs of one node, from ONE process (the reference's own
+ *      parallel seam is the per-candidate task loop, batchoptimize.cpp:102-114) ----
+ * The template list is cut into contiguous index ranges, one per device; every device rebuilds the DT3 volume itself
+ * from the scene lines (one host thread per device runs rebuild -> search) and the match records -- in top-k mode the
+ * k best of every shard (penalise + stable sort on each device) -- travel to the first device in ONE grouped RCCL
+ * send/recv per frame with exact sizes; no count exchange is needed because all shards live in this process.
+ * fdcm_sharded_search returns what fdcm_search returns for the whole list on one device (same records, same order);
+ * fdcm_sharded_search_topk returns what fdcm_topk returns for it.  devices = NULL means devices 0..n_devices-1.
+ * RCCL (librccl.so.1) is bound at run time, only when n_devices > 1 or FDCM_SHARDED_ALWAYS_COLLECTIVE is set (then a
+ * single shard also sends its records to itself through RCCL: a test hook for one-GPU machines). */
+#define FDCM_SHARDED_ALWAYS_COLLECTIVE 1
+typedef struct fdcm_sharded fdcm_sharded;
+int fdcm_sharded_create(const int* devices, int n_devices, const float* tmpl_lines, const int64_t* offsets /* n_templates+1 */,
+                        int64_t n_templates, int64_t depth, float dt3_coeff, float padding, int distance, int flags,
+                        fdcm_sharded** out);
+int fdcm_sharded_search(fdcm_sharded* s, const float* scene_lines, int64_t n_scene_lines, int64_t max_tmpl_lines,
+                        int64_t max_scene_lines, int optimizer, int64_t batch_size, fdcm_match** out, int64_t* n_out);
+/* penalty: -1 (none), FDCM_DEFAULT_PENALTY or FDCM_EXPONENTIAL_PENALTY(tau); at most k records per shard cross the links */
+int fdcm_sharded_search_topk(fdcm_sharded* s, const float* scene_lines, int64_t n_scene_lines, int64_t max_tmpl_lines,
+                             int64_t max_scene_lines, int optimizer, int64_t batch_size, int penalty, float tau, int64_t k,
+                             fdcm_match** out, int64_t* n_out);
+/* devices / shard_begin (n_devices + 1 entries: shard i holds templates [shard_begin[i], shard_begin[i+1])) may be NULL;
+ * collectives = grouped send/recv operations issued so far, bytes_moved = bytes they carried. */
+int fdcm_sharded_info(const fdcm_sharded* s, int* n_devices, int* devices, int64_t* shard_begin, int64_t* collectives,
+                      int64_t* bytes_moved);
+int fdcm_sharded_last_timing(const fdcm_sharded* s, int shard, fdcm_build_timing* bt, fdcm_search_timing* st);
+int fdcm_sharded_free(fdcm_sharded* s);
+
 /* ---- frame pipeline (throughput extension; the reference has no counterpart: its callers loop over frames
  *      and each search() blocks, python/src/matching.cpp:283-300).  One frame at the reference's sizes is
  *      latency bound on this GPU, so n_slots frames are kept in flight: each slot owns a feature map (own

@@ -11,7 +11,7 @@ import enum as _enum
 import numpy as _np
 
 from . import _capi
-from .engine import DeviceFeatureMap, DeviceTemplates, FramePipeline, search_raw, topk  # noqa: F401  (extensions)
+from .engine import DeviceFeatureMap, DeviceTemplates, FramePipeline, ShardedEngine, search_raw, topk  # noqa: F401  (extensions)
 
 __version__ = "0.10.0"  # API level of the reference this mirrors (openfdcm.cpp:43)
 

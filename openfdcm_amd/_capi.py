@@ -14,6 +14,7 @@ FDCM_OK = 0
 L2, L2_SQUARED, L1 = 0, 1, 2
 DEFAULT_OPTIMIZE, BATCH_OPTIMIZE, INDULGENT_OPTIMIZE = 0, 1, 2
 DEFAULT_PENALTY, EXPONENTIAL_PENALTY = 0, 1
+SHARDED_ALWAYS_COLLECTIVE = 1
 
 MATCH_DTYPE = np.dtype([("tmpl_idx", "<i4"), ("score", "<f4"), ("transform", "<f4", (6,))])
 assert MATCH_DTYPE.itemsize == 32
@@ -72,6 +73,14 @@ SYMBOLS = [
                                      C.POINTER(SearchTiming)]),
     ("fdcm_pipeline_slots", C.c_int, [_vp, C.POINTER(C.c_int)]),
     ("fdcm_pipeline_free", C.c_int, [_vp]),
+    ("fdcm_sharded_create", C.c_int, [C.POINTER(C.c_int), C.c_int, _fp, _i64p, C.c_int64, C.c_int64, C.c_float, C.c_float,
+                                      C.c_int, C.c_int, C.POINTER(_vp)]),
+    ("fdcm_sharded_search", C.c_int, [_vp, _fp, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int64, C.POINTER(_vp), _i64p]),
+    ("fdcm_sharded_search_topk", C.c_int, [_vp, _fp, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_float,
+                                           C.c_int64, C.POINTER(_vp), _i64p]),
+    ("fdcm_sharded_info", C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), _i64p, _i64p, _i64p]),
+    ("fdcm_sharded_last_timing", C.c_int, [_vp, C.c_int, C.POINTER(BuildTiming), C.POINTER(SearchTiming)]),
+    ("fdcm_sharded_free", C.c_int, [_vp]),
     ("fdcm_filter_in_range", C.c_int, [_fp, C.c_int64, _fp, C.c_float, C.c_float, _i64p, _i64p]),
     ("fdcm_penalize", C.c_int, [C.c_int, C.c_float, _vp, C.c_int64, _fp, C.c_int64]),
     ("fdcm_sort_matches", C.c_int, [_vp, C.c_int64]),

@@ -121,6 +121,7 @@ struct fdcm_featuremap {
     fdcm::DevBuf s_out;     // compacted matches
     fdcm::DevBuf s_work;    // search work list: valid pairs grouped by scene line
     fdcm::DevBuf s_tail;    // device tail (penalise + sort + top k) workspace
+    fdcm::DevBuf s_tail_out; // the k best of the device tail before their download
     int64_t last_n_out = 0; // matches of the last host-output search, still in s_out
     fdcm::DevBuf s_counter;
     fdcm::PinnedBuf s_stage;
@@ -153,6 +154,14 @@ void run_search(fdcm_featuremap* fm, const fdcm_templates* t, const float* scene
 // implemented in fdcm_tail.hip
 void run_topk(fdcm_featuremap* fm, const fdcm_templates* t, const fdcm_match* matches_device, int64_t n, int32_t base,
               int penalty, float tau, int64_t k, fdcm_match** out, int64_t* n_out);
+void run_topk_device(fdcm_featuremap* fm, const fdcm_templates* t, const fdcm_match* matches_device, int64_t n, int32_t base,
+                     int penalty, float tau, int64_t k, fdcm_match* out_device);
+// the device tail's total order on float bit patterns (-0 < +0, NaNs at the ends), for host-side merges
+inline unsigned ordered_key_host(float f) {
+    unsigned u;
+    __builtin_memcpy(&u, &f, 4);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
 // pooled pinned host buffers for match arrays returned to the caller (fdcm_host.cpp)
 fdcm_match* result_acquire(size_t bytes);
 void result_release(fdcm_match* m);

@@ -1,0 +1,370 @@
+// fdcm_sharded.cpp -- template shards over the GPUs of one node from ONE process (fdcm_sharded_* in include/fdcm.h).
+//
+// candidates of different templates are independent given the DT3 volume, so the template
+// list is split into contiguous index ranges, one per device; every device rebuilds the volume itself from the scene
+// lines (16 B per line; cheaper than moving V over a 153 GB/s xGMI link) and searches its range.  The reference's own
+// parallel seam is the per-candidate task loop of optimize<BatchOptimize> (batchoptimize.cpp:102-114); here the seam
+// is the template index.  One host thread per device runs rebuild -> search (the blocking entry points of fdcm.h),
+// then the match records -- or, in top-k mode, the k best of every shard -- travel to the first device in ONE grouped
+// RCCL send/recv.  The counts need no exchange: all shards live in this process, so every transfer has its exact size
+// and lands at its final offset; concatenation in shard order is the reference's positional order because the ranges
+// are contiguous (defaultmatch.cpp:51-86).
+//
+// RCCL is bound at run time (dlopen of librccl.so.1) so that the library neither needs it for single-GPU use nor
+// brings a second copy into a process that already holds one (PyTorch ships its own).
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "fdcm_internal.h"
+
+namespace {
+
+// ---- the few RCCL entry points this file uses (signatures of rccl.h; ncclResult_t 0 = success)
+typedef struct ncclComm* ncclComm_t;
+typedef int ncclResult_t;
+typedef int ncclDataType_t;
+constexpr ncclDataType_t kNcclUint8 = 1;  // ncclUint8 / ncclChar family: rccl.h enum ncclDataType_t {ncclInt8 = 0, ncclUint8 = 1, ...}
+
+struct Rccl {
+    void* handle = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string error;
+};
+
+Rccl& rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            r.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (r.handle) break;
+        }
+        if (!r.handle) { r.error = std::string("RCCL not found: ") + dlerror(); return; }
+        auto sym = [&](const char* s) { void* p = dlsym(r.handle, s); if (!p) r.error = std::string("RCCL symbol missing: ") + s; return p; };
+        r.CommInitAll = (decltype(r.CommInitAll))sym("ncclCommInitAll");
+        r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+        r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
+        r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
+        r.Send = (decltype(r.Send))sym("ncclSend");
+        r.Recv = (decltype(r.Recv))sym("ncclRecv");
+        r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+    });
+    return r;
+}
+
+void nccl_check(ncclResult_t rc, const char* what) {
+    if (rc != 0) throw std::string("RCCL error in ") + what + ": " + (rccl().GetErrorString ? rccl().GetErrorString(rc) : "?");
+}
+
+struct Shard {
+    int device = 0;
+    int64_t begin = 0, end = 0;        // template range
+    fdcm_templates* tset = nullptr;
+    fdcm_featuremap* fm = nullptr;
+    fdcm::DevBuf block;                // this shard's match records (search capacity of the frame)
+    fdcm::DevBuf best;                 // top-k mode: the shard's k best
+    hipStream_t stream = nullptr;      // the collective's stream on this device
+    // per-frame results of the worker
+    int rc = FDCM_OK;
+    std::string error;
+    int64_t n = 0;                     // records to send (matches, or min(k, matches) in top-k mode)
+    const fdcm_match* send_from = nullptr;
+    fdcm_build_timing bt{};
+    fdcm_search_timing st{};
+};
+
+}  // namespace
+
+struct fdcm_sharded {
+    std::vector<Shard> shards;
+    std::vector<ncclComm_t> comms;
+    bool always_collective = false;
+    int64_t depth = 0;
+    float coeff = 0.f, padding = 0.f;
+    int distance = 0;
+    fdcm::DevBuf gathered;   // on the first device: all shards' records back to back
+    int64_t collectives = 0; // grouped send/recv operations issued so far
+    int64_t bytes_moved = 0; // bytes that crossed between devices (or through RCCL) so far
+};
+
+namespace fdcm {
+const char* last_error_cstr();
+}
+
+using namespace fdcm;
+
+namespace {
+
+template <class F>
+int guarded_s(F&& f) {
+    try {
+        f();
+        return FDCM_OK;
+    } catch (const HipError& e) {
+        set_error(std::string("HIP error: ") + hipGetErrorString(e.code) + " in " + e.what);
+        return FDCM_EHIP;
+    } catch (const std::string& s) {
+        set_error(s);
+        return FDCM_EINVAL;
+    } catch (const std::exception& e) {
+        set_error(e.what());
+        return FDCM_EINTERNAL;
+    } catch (...) {
+        set_error("unknown error");
+        return FDCM_EINTERNAL;
+    }
+}
+
+// rebuild -> search on every shard, one host thread per device; top-k mode adds the device tail per shard
+void run_shards(fdcm_sharded* s, const float* scene, int64_t n_scene, int64_t maxT, int64_t maxS, int optimizer, int64_t batch,
+                bool topk, int penalty, float tau, int64_t k) {
+    std::vector<std::thread> th;
+    for (size_t i = 0; i < s->shards.size(); ++i) {
+        th.emplace_back([&, i] {
+            Shard& sh = s->shards[i];
+            sh.rc = FDCM_OK; sh.n = 0; sh.send_from = nullptr; sh.error.clear();
+            auto fail = [&](int rc) { sh.rc = rc; sh.error = fdcm_last_error(); };
+            int rc = fdcm_set_device(sh.device);
+            if (rc != FDCM_OK) return fail(rc);
+            rc = sh.fm ? fdcm_featuremap_rebuild(sh.fm, scene, n_scene)
+                       : fdcm_featuremap_build(scene, n_scene, s->depth, s->coeff, s->padding, s->distance, &sh.fm);
+            if (rc != FDCM_OK) return fail(rc);
+            int64_t cap = 0;
+            rc = fdcm_search_capacity(sh.tset, n_scene, maxT, maxS, &cap);
+            if (rc != FDCM_OK) return fail(rc);
+            try {
+                FDCM_HIP(hipSetDevice(sh.device));
+                sh.block.reserve(std::max<size_t>(32, (size_t)cap * sizeof(fdcm_match)));
+            } catch (const HipError& e) {
+                set_error(std::string("HIP error: ") + hipGetErrorString(e.code) + " in " + e.what);
+                return fail(FDCM_EHIP);
+            }
+            int64_t n = 0;
+            rc = fdcm_search_device(sh.fm, sh.tset, scene, n_scene, maxT, maxS, optimizer, batch, (int32_t)sh.begin,
+                                    sh.block.as<fdcm_match>(), &n);
+            if (rc != FDCM_OK) return fail(rc);
+            (void)fdcm_featuremap_last_timing(sh.fm, &sh.bt);
+            (void)fdcm_search_last_timing(sh.fm, &sh.st);
+            sh.n = n;
+            sh.send_from = sh.block.as<fdcm_match>();
+            if (topk) {
+                try {
+                    const int64_t kk = std::min<int64_t>(std::max<int64_t>(k, 0), n);
+                    FDCM_HIP(hipSetDevice(sh.device));
+                    sh.best.reserve(std::max<size_t>(32, (size_t)kk * sizeof(fdcm_match)));
+                    fdcm::run_topk_device(sh.fm, sh.tset, sh.block.as<fdcm_match>(), n, (int32_t)sh.begin, penalty, tau, kk,
+                                          sh.best.as<fdcm_match>());
+                    sh.n = kk;
+                    sh.send_from = sh.best.as<fdcm_match>();
+                } catch (const HipError& e) {
+                    set_error(std::string("HIP error: ") + hipGetErrorString(e.code) + " in " + e.what);
+                    return fail(FDCM_EHIP);
+                } catch (const std::string& e) {
+                    set_error(e);
+                    return fail(FDCM_EINVAL);
+                }
+            }
+        });
+    }
+    for (auto& t : th) t.join();
+    for (auto& sh : s->shards)
+        if (sh.rc != FDCM_OK) throw std::string("shard on device ") + std::to_string(sh.device) + ": " + sh.error;
+}
+
+// All shards' records to the first device, back to back in shard order: ONE grouped send/recv with exact sizes.
+// Returns the total record count; the records are at s->gathered on device shards[0].device, complete when the
+// first shard's stream has been synchronised (done here).
+int64_t gather_to_first(fdcm_sharded* s) {
+    std::vector<int64_t> off(s->shards.size() + 1, 0);
+    for (size_t i = 0; i < s->shards.size(); ++i) off[i + 1] = off[i] + s->shards[i].n;
+    const int64_t total = off.back();
+    Shard& root = s->shards[0];
+    FDCM_HIP(hipSetDevice(root.device));
+    s->gathered.reserve(std::max<size_t>(32, (size_t)total * sizeof(fdcm_match)));
+    fdcm_match* dst = s->gathered.as<fdcm_match>();
+    const bool single = s->shards.size() == 1 && !s->always_collective;
+    if (single) {  // nothing to exchange: the records already are on the first (only) device
+        if (total) FDCM_HIP(hipMemcpyAsync(dst, root.send_from, (size_t)total * sizeof(fdcm_match), hipMemcpyDeviceToDevice, root.stream));
+        FDCM_HIP(hipStreamSynchronize(root.stream));
+        return total;
+    }
+    Rccl& R = rccl();
+    bool any = false;
+    nccl_check(R.GroupStart(), "ncclGroupStart");
+    for (size_t i = 0; i < s->shards.size(); ++i) {
+        Shard& sh = s->shards[i];
+        if (sh.n == 0) continue;
+        const size_t bytes = (size_t)sh.n * sizeof(fdcm_match);
+        nccl_check(R.Send(sh.send_from, bytes, kNcclUint8, 0, s->comms[i], sh.stream), "ncclSend");
+        nccl_check(R.Recv(dst + off[i], bytes, kNcclUint8, (int)i, s->comms[0], root.stream), "ncclRecv");
+        s->bytes_moved += (int64_t)bytes;
+        any = true;
+    }
+    nccl_check(R.GroupEnd(), "ncclGroupEnd");
+    if (any) ++s->collectives;
+    for (auto& sh : s->shards) {  // the send buffers are reused by the next frame
+        FDCM_HIP(hipSetDevice(sh.device));
+        FDCM_HIP(hipStreamSynchronize(sh.stream));
+    }
+    return total;
+}
+
+fdcm_match* download(fdcm_sharded* s, int64_t total) {
+    Shard& root = s->shards[0];
+    fdcm_match* out = result_acquire(std::max<size_t>(1, (size_t)total) * sizeof(fdcm_match));
+    try {
+        FDCM_HIP(hipSetDevice(root.device));
+        if (total) {
+            FDCM_HIP(hipMemcpyAsync(out, s->gathered.p, (size_t)total * sizeof(fdcm_match), hipMemcpyDeviceToHost, root.stream));
+            FDCM_HIP(hipStreamSynchronize(root.stream));
+        }
+    } catch (...) {
+        result_release(out);
+        throw;
+    }
+    return out;
+}
+
+void destroy_sharded(fdcm_sharded* s) {
+    if (!s) return;
+    for (size_t i = 0; i < s->comms.size(); ++i)
+        if (s->comms[i] && rccl().CommDestroy) (void)rccl().CommDestroy(s->comms[i]);
+    for (auto& sh : s->shards) {
+        (void)hipSetDevice(sh.device);
+        if (sh.stream) { (void)hipStreamSynchronize(sh.stream); (void)hipStreamDestroy(sh.stream); }
+        if (sh.fm) (void)fdcm_featuremap_free(sh.fm);
+        if (sh.tset) (void)fdcm_templates_free(sh.tset);
+        sh.block.release();
+        sh.best.release();
+    }
+    if (!s->shards.empty()) (void)hipSetDevice(s->shards[0].device);
+    s->gathered.release();
+    delete s;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fdcm_sharded_create(const int* devices, int n_devices, const float* tmpl_lines, const int64_t* offsets, int64_t n_templates,
+                        int64_t depth, float dt3_coeff, float padding, int distance, int flags, fdcm_sharded** out) {
+    fdcm_sharded* s = nullptr;
+    int rc = guarded_s([&] {
+        if (!out) throw std::string("out is null");
+        *out = nullptr;
+        if (n_devices < 1 || n_devices > 64) throw std::string("n_devices must be 1..64");
+        if (n_templates < 0 || !offsets || (n_templates > 0 && offsets[n_templates] > 0 && !tmpl_lines)) throw std::string("bad templates");
+        if (depth < 0 || distance < FDCM_L2 || distance > FDCM_L1) throw std::string("bad feature-map parameters");
+        int have = 0;
+        FDCM_HIP(hipGetDeviceCount(&have));
+        s = new fdcm_sharded();
+        s->depth = depth; s->coeff = dt3_coeff; s->padding = padding; s->distance = distance;
+        s->always_collective = (flags & FDCM_SHARDED_ALWAYS_COLLECTIVE) != 0;
+        s->shards.resize((size_t)n_devices);
+        std::vector<int> devs((size_t)n_devices);
+        for (int i = 0; i < n_devices; ++i) {
+            devs[i] = devices ? devices[i] : i;
+            if (devs[i] < 0 || devs[i] >= have) throw std::string("device ") + std::to_string(devs[i]) + " does not exist";
+            for (int j = 0; j < i; ++j)
+                if (devs[j] == devs[i]) throw std::string("a device is listed twice");
+        }
+        for (int i = 0; i < n_devices; ++i) {
+            Shard& sh = s->shards[(size_t)i];
+            sh.device = devs[i];
+            // contiguous ranges: shard r gets [r T / n, (r + 1) T / n)  
+            sh.begin = n_templates * i / n_devices;
+            sh.end = n_templates * (i + 1) / n_devices;
+            int r = fdcm_set_device(sh.device);
+            if (r != FDCM_OK) throw std::string(fdcm_last_error());
+            std::vector<int64_t> off((size_t)(sh.end - sh.begin) + 1);
+            for (int64_t t = sh.begin; t <= sh.end; ++t) off[(size_t)(t - sh.begin)] = offsets[t] - offsets[sh.begin];
+            r = fdcm_templates_create(tmpl_lines ? tmpl_lines + 4 * offsets[sh.begin] : nullptr, off.data(), sh.end - sh.begin, &sh.tset);
+            if (r != FDCM_OK) throw std::string(fdcm_last_error());
+            FDCM_HIP(hipStreamCreateWithFlags(&sh.stream, hipStreamNonBlocking));
+        }
+        if (n_devices > 1 || s->always_collective) {
+            Rccl& R = rccl();
+            if (!R.error.empty()) throw R.error;
+            s->comms.assign((size_t)n_devices, nullptr);
+            nccl_check(R.CommInitAll(s->comms.data(), n_devices, devs.data()), "ncclCommInitAll");
+        }
+        *out = s;
+    });
+    if (rc != FDCM_OK) destroy_sharded(s);
+    return rc;
+}
+
+int fdcm_sharded_free(fdcm_sharded* s) {
+    return guarded_s([&] { destroy_sharded(s); });
+}
+
+int fdcm_sharded_info(const fdcm_sharded* s, int* n_devices, int* devices, int64_t* shard_begin, int64_t* collectives,
+                      int64_t* bytes_moved) {
+    return guarded_s([&] {
+        if (!s) throw std::string("null handle");
+        const int n = (int)s->shards.size();
+        if (n_devices) *n_devices = n;
+        for (int i = 0; i < n; ++i) {
+            if (devices) devices[i] = s->shards[(size_t)i].device;
+            if (shard_begin) shard_begin[i] = s->shards[(size_t)i].begin;
+        }
+        if (shard_begin) shard_begin[n] = s->shards.back().end;
+        if (collectives) *collectives = s->collectives;
+        if (bytes_moved) *bytes_moved = s->bytes_moved;
+    });
+}
+
+int fdcm_sharded_search(fdcm_sharded* s, const float* scene_lines, int64_t n_scene_lines, int64_t max_tmpl_lines,
+                        int64_t max_scene_lines, int optimizer, int64_t batch_size, fdcm_match** out, int64_t* n_out) {
+    return guarded_s([&] {
+        if (!s || !out || !n_out) throw std::string("null argument");
+        *out = nullptr; *n_out = 0;
+        run_shards(s, scene_lines, n_scene_lines, max_tmpl_lines, max_scene_lines, optimizer, batch_size, false, -1, 1.f, 0);
+        const int64_t total = gather_to_first(s);
+        *out = download(s, total);
+        *n_out = total;
+    });
+}
+
+int fdcm_sharded_search_topk(fdcm_sharded* s, const float* scene_lines, int64_t n_scene_lines, int64_t max_tmpl_lines,
+                             int64_t max_scene_lines, int optimizer, int64_t batch_size, int penalty, float tau, int64_t k,
+                             fdcm_match** out, int64_t* n_out) {
+    return guarded_s([&] {
+        if (!s || !out || !n_out) throw std::string("null argument");
+        if (penalty < -1 || penalty > FDCM_EXPONENTIAL_PENALTY) throw std::string("unknown penalty");
+        if (k < 0) throw std::string("k must be >= 0");
+        *out = nullptr; *n_out = 0;
+        run_shards(s, scene_lines, n_scene_lines, max_tmpl_lines, max_scene_lines, optimizer, batch_size, true, penalty, tau, k);
+        const int64_t total = gather_to_first(s);  // at most k records per shard cross the links
+        fdcm_match* all = download(s, total);
+        // every shard's list is ascending by score with ties in positional order, and the lists arrive in shard order:
+        // a stable sort by score keeps ties in (shard, position) = global positional order
+        std::stable_sort(all, all + total, [](const fdcm_match& a, const fdcm_match& b) {
+            return fdcm::ordered_key_host(a.score) < fdcm::ordered_key_host(b.score);
+        });
+        *out = all;
+        *n_out = std::min<int64_t>(k, total);
+    });
+}
+
+int fdcm_sharded_last_timing(const fdcm_sharded* s, int shard, fdcm_build_timing* bt, fdcm_search_timing* st) {
+    return guarded_s([&] {
+        if (!s || shard < 0 || shard >= (int)s->shards.size()) throw std::string("bad shard index");
+        if (bt) *bt = s->shards[(size_t)shard].bt;
+        if (st) *st = s->shards[(size_t)shard].st;
+    });
+}
+
+}  // extern "C"

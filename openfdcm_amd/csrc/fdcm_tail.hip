@@ -7,8 +7,8 @@
 // (defaultpenalty.cpp:37-41, exponentialpenalty.cpp:42-46), is computed on the host with the host's
 // libm exactly as the reference does; the device only divides (IEEE, correctly rounded), so the
 // penalised scores are the reference's bits.  Order: ascending score, ties in positional order
-// (the reference's std::sort leaves ties unspecified): a stable radix sort of (score, position).
-#include <hipcub/hipcub.hpp>
+// (the reference's std::sort leaves ties unspecified): a stable radix sort of (score, position) with rocPRIM.
+#include <rocprim/device/device_radix_sort.hpp>
 
 #include <cmath>
 #include <cstring>
@@ -46,27 +46,25 @@ __global__ void k_tail_gather(const fdcm_match* __restrict__ m, const unsigned* 
     out[j] = r;
 }
 
-void run_topk(fdcm_featuremap* fm, const fdcm_templates* t, const fdcm_match* matches_device, int64_t n, int32_t base,
-              int penalty, float tau, int64_t k, fdcm_match** out, int64_t* n_out) {
-    *out = nullptr;
-    *n_out = 0;
+// The k best of n device-resident matches, penalised, into out_device (k <= n, both on fm's device); returns when
+// the records are complete.
+void run_topk_device(fdcm_featuremap* fm, const fdcm_templates* t, const fdcm_match* matches_device, int64_t n, int32_t base,
+                     int penalty, float tau, int64_t k, fdcm_match* out_device) {
     FDCM_HIP(hipSetDevice(fm->device));
     if (!fm->stream) FDCM_HIP(hipStreamCreateWithFlags(&fm->stream, hipStreamNonBlocking));
     hipStream_t st = fm->stream;
-    k = std::min<int64_t>(std::max<int64_t>(k, 0), n);
-    *out = result_acquire(std::max<size_t>(1, (size_t)k) * sizeof(fdcm_match));
-    if (k == 0) return;
+    if (k <= 0) return;
+    if (k > n) throw std::string("k exceeds the number of matches");
     if (n > 0x7fffffffll) throw std::string("more than 2^31 matches are not supported by the device tail");
     // ---- denominators on the host (getTemplateLengths + the penalty's formula), uploaded through pinned staging
     const bool pen = penalty >= 0;
     const size_t a256 = 255;
     const size_t o_den = 0, o_keys = ((size_t)t->T * 4 + a256) & ~a256, o_keys2 = o_keys + (((size_t)n * 4 + a256) & ~a256),
                  o_idx = o_keys2 + (((size_t)n * 4 + a256) & ~a256), o_idx2 = o_idx + (((size_t)n * 4 + a256) & ~a256),
-                 o_ps = o_idx2 + (((size_t)n * 4 + a256) & ~a256), o_out = o_ps + (((size_t)n * 4 + a256) & ~a256),
-                 o_tmp = o_out + (((size_t)k * sizeof(fdcm_match) + a256) & ~a256);
+                 o_ps = o_idx2 + (((size_t)n * 4 + a256) & ~a256), o_tmp = o_ps + (((size_t)n * 4 + a256) & ~a256);
     size_t tmp_bytes = 0;
-    FDCM_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, (const unsigned*)nullptr, (unsigned*)nullptr,
-                                                (const unsigned*)nullptr, (unsigned*)nullptr, (int)n, 0, 32, st));
+    FDCM_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, (const unsigned*)nullptr, (unsigned*)nullptr,
+                                       (const unsigned*)nullptr, (unsigned*)nullptr, (size_t)n, 0, 32, st));
     fm->s_tail.reserve(o_tmp + tmp_bytes + 256);
     char* d = (char*)fm->s_tail.p;
     if (pen) {
@@ -86,13 +84,27 @@ void run_topk(fdcm_featuremap* fm, const fdcm_templates* t, const fdcm_match* ma
     hipLaunchKernelGGL(k_tail_keys, dim3(nb), dim3(256), 0, st, matches_device, (long long)n,
                        pen ? (const float*)(d + o_den) : nullptr, (int)base, (int)t->T, (unsigned*)(d + o_keys),
                        (unsigned*)(d + o_idx), (float*)(d + o_ps));
-    FDCM_HIP(hipcub::DeviceRadixSort::SortPairs(d + o_tmp, tmp_bytes, (const unsigned*)(d + o_keys), (unsigned*)(d + o_keys2),
-                                                (const unsigned*)(d + o_idx), (unsigned*)(d + o_idx2), (int)n, 0, 32, st));
+    FDCM_HIP(rocprim::radix_sort_pairs(d + o_tmp, tmp_bytes, (const unsigned*)(d + o_keys), (unsigned*)(d + o_keys2),
+                                       (const unsigned*)(d + o_idx), (unsigned*)(d + o_idx2), (size_t)n, 0, 32, st));
     hipLaunchKernelGGL(k_tail_gather, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, st, matches_device,
-                       (const unsigned*)(d + o_idx2), (const float*)(d + o_ps), (long long)k, (fdcm_match*)(d + o_out));
+                       (const unsigned*)(d + o_idx2), (const float*)(d + o_ps), (long long)k, out_device);
     FDCM_HIP(hipGetLastError());
-    FDCM_HIP(hipMemcpyAsync(*out, d + o_out, (size_t)k * sizeof(fdcm_match), hipMemcpyDeviceToHost, st));
     FDCM_HIP(hipStreamSynchronize(st));
+}
+
+void run_topk(fdcm_featuremap* fm, const fdcm_templates* t, const fdcm_match* matches_device, int64_t n, int32_t base,
+              int penalty, float tau, int64_t k, fdcm_match** out, int64_t* n_out) {
+    *out = nullptr;
+    *n_out = 0;
+    FDCM_HIP(hipSetDevice(fm->device));
+    if (!fm->stream) FDCM_HIP(hipStreamCreateWithFlags(&fm->stream, hipStreamNonBlocking));
+    k = std::min<int64_t>(std::max<int64_t>(k, 0), n);
+    *out = result_acquire(std::max<size_t>(1, (size_t)k) * sizeof(fdcm_match));
+    if (k == 0) return;
+    fm->s_tail_out.reserve((size_t)k * sizeof(fdcm_match));
+    run_topk_device(fm, t, matches_device, n, base, penalty, tau, k, fm->s_tail_out.as<fdcm_match>());
+    FDCM_HIP(hipMemcpyAsync(*out, fm->s_tail_out.p, (size_t)k * sizeof(fdcm_match), hipMemcpyDeviceToHost, fm->stream));
+    FDCM_HIP(hipStreamSynchronize(fm->stream));
     *n_out = k;
 }
 

@@ -229,3 +229,66 @@ def topk(fm, templates, k, penalty=None, tau=1.0, tmpl_index_base=0, device_ptr=
                                     int(tmpl_index_base), -1 if penalty is None else int(penalty), float(tau), int(k),
                                     C.byref(out), C.byref(n_out)))
     return _adopt_matches(out, n_out.value)
+
+
+class ShardedEngine:
+    """Template shards over several GPUs of this node from one process (fdcm_sharded_* in include/fdcm.h): every
+    device rebuilds the DT3 volume and searches a contiguous template range; the records (or the k best of every
+    shard) reach the first device in one grouped RCCL send/recv per frame.  Returns what the single-device calls
+    return for the whole template list."""
+
+    def __init__(self, templates, devices=None, n_devices=None, depth=30, coeff=5.0, padding=2.2, distance=capi.L2,
+                 always_collective=False):
+        flat, offsets = capi.pack_templates(templates)
+        if devices is not None:
+            n_devices = len(devices)
+            dev = (C.c_int * n_devices)(*devices)
+        else:
+            n_devices = n_devices or 1
+            dev = None
+        h = C.c_void_p()
+        capi.check(capi.lib().fdcm_sharded_create(dev, n_devices, capi.fptr(flat) if flat.size else None,
+                                                  offsets.ctypes.data_as(C.POINTER(C.c_int64)), len(templates), depth, coeff,
+                                                  padding, distance, capi.SHARDED_ALWAYS_COLLECTIVE if always_collective else 0,
+                                                  C.byref(h)))
+        self._h, self.n_devices, self.n_templates = h, n_devices, len(templates)
+
+    def info(self):
+        n = C.c_int()
+        devs = (C.c_int * self.n_devices)()
+        begin = (C.c_int64 * (self.n_devices + 1))()
+        coll, moved = C.c_int64(), C.c_int64()
+        capi.check(capi.lib().fdcm_sharded_info(self._h, C.byref(n), devs, begin, C.byref(coll), C.byref(moved)))
+        return {"devices": list(devs), "shard_begin": list(begin), "collectives": coll.value, "bytes_moved": moved.value}
+
+    def search(self, scene, max_tmpl_lines, max_scene_lines, optimizer=capi.BATCH_OPTIMIZE, batch_size=10):
+        rec = capi.as_records(scene)
+        out, n = C.c_void_p(), C.c_int64()
+        capi.check(capi.lib().fdcm_sharded_search(self._h, capi.fptr(rec) if rec.size else None, rec.shape[0], max_tmpl_lines,
+                                                  max_scene_lines, optimizer, batch_size, C.byref(out), C.byref(n)))
+        return _adopt_matches(out, n.value)
+
+    def search_topk(self, scene, max_tmpl_lines, max_scene_lines, k, penalty=None, tau=1.0, optimizer=capi.BATCH_OPTIMIZE,
+                    batch_size=10):
+        rec = capi.as_records(scene)
+        out, n = C.c_void_p(), C.c_int64()
+        capi.check(capi.lib().fdcm_sharded_search_topk(self._h, capi.fptr(rec) if rec.size else None, rec.shape[0],
+                                                       max_tmpl_lines, max_scene_lines, optimizer, batch_size,
+                                                       -1 if penalty is None else penalty, tau, k, C.byref(out), C.byref(n)))
+        return _adopt_matches(out, n.value)
+
+    def timing(self, shard=0):
+        bt, st = capi.BuildTiming(), capi.SearchTiming()
+        capi.check(capi.lib().fdcm_sharded_last_timing(self._h, shard, C.byref(bt), C.byref(st)))
+        return ({k: getattr(bt, k) for k, _ in bt._fields_}, {k: getattr(st, k) for k, _ in st._fields_})
+
+    def close(self):
+        if self._h:
+            capi.check(capi.lib().fdcm_sharded_free(self._h))
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -541,3 +541,56 @@ def test_frame_pipeline_reports_a_failed_frame_and_keeps_going(amd):
     t2, t3 = pipe.submit(good), pipe.submit(good)  # t3 runs on the slot whose last frame failed
     assert pipe.wait(t2).tobytes() == first.tobytes() and pipe.wait(t3).tobytes() == first.tobytes()
     pipe.close()
+
+
+# ---------------------------------------------------------------- template shards behind the C ABI (fdcm_sharded_*)
+@pytest.mark.parametrize("always_collective", [False, True], ids=["direct", "through-rccl"])
+def test_sharded_engine_one_device(amd, always_collective):
+    """fdcm_sharded_* with one device (the test box has one GPU).  With FDCM_SHARDED_ALWAYS_COLLECTIVE the shard's
+    records go to the first device through the grouped RCCL send/recv that multi-GPU runs use (one per frame), so the
+    driver's suite executes the RCCL path.  Full list and top-k against the oracle and the single-device calls."""
+    import ctypes as C
+    from openfdcm_amd import synthetic, _capi
+    from openfdcm_amd.engine import DeviceFeatureMap, DeviceTemplates, ShardedEngine, search_raw, topk
+    S = 256
+    tmpls = synthetic.templates(30, 13, S, 12) + [np.zeros((4, 0), np.float32)] + synthetic.templates(9, 32, S, 13)
+    eng = ShardedEngine(tmpls, n_devices=1, depth=30, coeff=5.0, padding=1.0, distance=O.L2, always_collective=always_collective)
+    assert eng.info()["shard_begin"] == [0, len(tmpls)]
+    frames = 0
+    for seed, n_lines in [(11, 60), (12, 45), (13, 0)]:
+        scene = synthetic.scene(S, n_lines, seed) if n_lines else np.zeros((4, 0), np.float32)
+        got = eng.search(scene, 4, 4, _capi.BATCH_OPTIMIZE, 10)
+        frames += 1
+        if n_lines == 0:
+            assert len(got) == 0
+            continue
+        orc = O.build(scene, depth=30, coeff=5.0, padding=1.0, distance=O.L2, nthreads=4)
+        want = O.search(orc, tmpls, scene, 4, 4, kind=O.BATCH_OPTIMIZE, batch=10, nthreads=4)
+        assert assert_matches_close(got, want, f"sharded search, scene {seed}"), "not bit-identical"
+        # top-k: the shard's k best through the same exchange == fdcm_topk on one device
+        fm = DeviceFeatureMap.build(scene, depth=30, coeff=5.0, padding=1.0, distance=O.L2)
+        tset = DeviceTemplates(tmpls)
+        search_raw(fm, tset, scene, 4, 4, _capi.BATCH_OPTIMIZE, 10)
+        for k in (1, 25, len(want) + 10):
+            a = eng.search_topk(scene, 4, 4, k, penalty=1, tau=1.5)
+            frames += 1
+            b = topk(fm, tset, k, 1, 1.5)
+            assert a.tobytes() == b.tobytes(), (seed, k)
+    info = eng.info()
+    if always_collective:
+        assert info["collectives"] >= frames - 1 and info["bytes_moved"] > 0  # the empty frame moves nothing
+    else:
+        assert info["collectives"] == 0
+    bt, st = eng.timing(0)
+    assert bt["pass2_ms"] >= 0 and st["candidates"] >= 0
+    eng.close()
+
+
+def test_sharded_engine_rejects_bad_devices(amd):
+    from openfdcm_amd import synthetic, _capi
+    from openfdcm_amd.engine import ShardedEngine
+    tmpls = synthetic.templates(4, 5, 128, 3)
+    with pytest.raises(_capi.FdcmError, match="does not exist"):
+        ShardedEngine(tmpls, devices=[0, 63])
+    with pytest.raises(_capi.FdcmError, match="twice"):
+        ShardedEngine(tmpls, devices=[0, 0])
