@@ -206,7 +206,10 @@ int fdcm_sort_matches(fdcm_match* matches, int64_t n);
  *      `fm`.  penalty: FDCM_DEFAULT_PENALTY, FDCM_EXPONENTIAL_PENALTY (tau) or -1 for none.  Returns min(k, n)
  *      records in ascending penalised score, ties in positional order (the reference's std::sort leaves ties
  *      unspecified); scores are the reference's bits (denominators from the host libm, IEEE division on the
- *      device).  Release with fdcm_matches_free.  In sharded runs each rank sends its k best instead of all. ---- */
+ *      device).  A record whose tmpl_idx - tmpl_index_base is outside the template set gets a NaN score and
+ *      sorts last (fdcm_penalize on the host reports an error for the same input, like the reference's
+ *      templatelengths.at()).  Release with fdcm_matches_free.  In sharded runs each rank sends its k best instead
+ *      of all. ---- */
 int fdcm_topk(fdcm_featuremap* fm, const fdcm_templates* templates, const fdcm_match* matches_device, int64_t n,
               int32_t tmpl_index_base, int penalty, float tau, int64_t k, fdcm_match** out, int64_t* n_out);
 

@@ -40,8 +40,17 @@ FDCM_HD float std_max(float a, float b) { return (a < b) ? b : a; }
 // Bit-exact restatement of this image's glibc (2.35) atanf, sysdeps/ieee754/flt-32/s_atanf.c
 // (fdlibm float port: argument reduction to 5 intervals + an 11-term odd/even split polynomial).
 // getAngle (math.h:295-299) is atanf(dy/dx) and decides the orientation bin of every aligned
-// template line, so the device must reproduce the host libm.  tests/test_host_math.py checks
-// equality with libm atanf on all 2^32 inputs on the CPU.
+// template line, so the device must reproduce the host libm.  tests/test_capi_load.py checks equality with
+// libm atanf on every 257th of the 2^32 inputs (and on all of them in its slow test) through
+// fdcm_selftest_atanf; the first search of a process runs a sampled check as well and refuses to run on a
+// host whose libm disagrees (a newer glibc ships a correctly rounded atanf).
+//
+// The algorithm and constants are those of fdlibm's s_atanf.c, which carries this notice:
+//   Copyright (C) 1993 by Sun Microsystems, Inc. All rights reserved.
+//   Developed at SunPro, a Sun Microsystems, Inc. business.
+//   Permission to use, copy, modify, and distribute this software is freely granted, provided that this
+//   notice is preserved.
+// (float conversion of the original by Ian Lance Taylor, Cygnus Support.)
 FDCM_HD float atanf_glibc(float x) {
     const float atanhi[4] = {4.6364760399e-01f, 7.8539812565e-01f, 9.8279368877e-01f, 1.5707962513e+00f};
     const float atanlo[4] = {5.0121582440e-09f, 3.7748947079e-08f, 3.4473217170e-08f, 7.5497894159e-08f};

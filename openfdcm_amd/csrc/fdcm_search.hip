@@ -65,7 +65,7 @@ struct SearchParams {
     fdcm_match* records;
     int* flags;
     int* evals;
-    unsigned long long* counters;  // [0] translations evaluated by the rule, [1] volume reads, [2] matches
+    unsigned long long* counters;  // [0] translations evaluated by the rule, [1] unused, [2] matches
 };
 
 static constexpr int kWavesPerBlock = 4;
@@ -81,22 +81,14 @@ __device__ __forceinline__ float wave_max_f(float v) {
 
 // evaluate<Dt3Cpu> for one line and one translation, dt3cpu.cpp:153-173.  L = per-wave LDS lines
 // (x1,y1,x2,y2,bin), off = sceneTranslation + translation.
-// XF: read the x-fastest copy (W and H are passed swapped by the caller: the copy is [k][y][x]).
-template <bool XF>
 __device__ __forceinline__ float line_value(const float* __restrict__ vol, const float* L, int i, float offx,
                                             float offy, size_t W, size_t H) {
     const float* l = L + 5 * i;
     const int x1 = (int)(l[0] + offx), y1 = (int)(l[1] + offy);  // translate then cast<int>()
     const int x2 = (int)(l[2] + offx), y2 = (int)(l[3] + offy);
     const size_t bin = (size_t)__float_as_int(l[4]);
-    float a, b;
-    if (XF) {
-        a = vol[(bin * H + (size_t)y1) * W + (size_t)x1];
-        b = vol[(bin * H + (size_t)y2) * W + (size_t)x2];
-    } else {
-        a = vol[(bin * W + (size_t)x1) * H + (size_t)y1];
-        b = vol[(bin * W + (size_t)x2) * H + (size_t)y2];
-    }
+    const float a = vol[(bin * W + (size_t)x1) * H + (size_t)y1];
+    const float b = vol[(bin * W + (size_t)x2) * H + (size_t)y2];
     return f_abs(a - b);
 }
 
@@ -104,7 +96,6 @@ __device__ __forceinline__ float line_value(const float* __restrict__ vol, const
 // Packet4f): p0 = packet(0), p1 = packet(4); blocks of 8: p0 += packet(i), p1 += packet(i+4);
 // p0 += p1; optional trailing packet; predux (p0+p2)+(p1+p3); scalar tail in order.
 // Lane h = 0 owns p0, lane h = 1 owns p1 of the same translation; the result is valid in h = 0.
-template <bool XF>
 __device__ __forceinline__ float pair_score(const float* __restrict__ vol, const float* L, int n, float offx,
                                             float offy, size_t W, size_t H, int h, bool active) {
     const int aligned2 = (n / 8) * 8, aligned = (n / 4) * 4;
@@ -117,13 +108,13 @@ __device__ __forceinline__ float pair_score(const float* __restrict__ vol, const
                 const int b = 8 * i + 4 * h;
                 float v[4];
 #pragma unroll
-                for (int l = 0; l < 4; ++l) v[l] = line_value<XF>(vol, L, b + l, offx, offy, W, H);
+                for (int l = 0; l < 4; ++l) v[l] = line_value(vol, L, b + l, offx, offy, W, H);
 #pragma unroll
                 for (int l = 0; l < 4; ++l) acc[l] = acc[l] + v[l];
             }
         } else if (aligned == 4 && h == 0) {
 #pragma unroll
-            for (int l = 0; l < 4; ++l) acc[l] = line_value<XF>(vol, L, l, offx, offy, W, H);
+            for (int l = 0; l < 4; ++l) acc[l] = line_value(vol, L, l, offx, offy, W, H);
         }
     }
     float res = 0.f;
@@ -135,13 +126,13 @@ __device__ __forceinline__ float pair_score(const float* __restrict__ vol, const
         if (aligned) {
             if (aligned >= 8 && aligned > aligned2) {
 #pragma unroll
-                for (int l = 0; l < 4; ++l) acc[l] = acc[l] + line_value<XF>(vol, L, aligned2 + l, offx, offy, W, H);
+                for (int l = 0; l < 4; ++l) acc[l] = acc[l] + line_value(vol, L, aligned2 + l, offx, offy, W, H);
             }
             res = (acc[0] + acc[2]) + (acc[1] + acc[3]);
-            for (int idx = aligned; idx < n; ++idx) res = res + line_value<XF>(vol, L, idx, offx, offy, W, H);
+            for (int idx = aligned; idx < n; ++idx) res = res + line_value(vol, L, idx, offx, offy, W, H);
         } else if (n > 0) {
-            res = line_value<XF>(vol, L, 0, offx, offy, W, H);
-            for (int idx = 1; idx < n; ++idx) res = res + line_value<XF>(vol, L, idx, offx, offy, W, H);
+            res = line_value(vol, L, 0, offx, offy, W, H);
+            for (int idx = 1; idx < n; ++idx) res = res + line_value(vol, L, idx, offx, offy, W, H);
         }
     }
     return res;
@@ -160,7 +151,6 @@ struct OptState {
 
 // Score multipliers k_from, k_from + dir, ... (cnt of them) into sc[dst ..]; with_zero additionally
 // scores translation (0,0) into sc[2 WIN].  32 translations per gather round.
-template <bool XF>
 __device__ __forceinline__ void score_range(const float* __restrict__ vol, const OptState& o, int dir, long long k_from,
                                             int cnt, int dst, bool with_zero) {
     const int h = o.lane >> 5, slot = o.lane & 31;  // neighbouring lanes = neighbouring translations
@@ -171,7 +161,7 @@ __device__ __forceinline__ void score_range(const float* __restrict__ vol, const
         const long long k = idx < 0 ? 0 : k_from + (long long)dir * idx;
         // translation = float(k) * scaled_align_vec (:58/:81); Point2{0,0} for the initial score (:36)
         const float trx = idx < 0 ? 0.f : (float)k * o.savx, try_ = idx < 0 ? 0.f : (float)k * o.savy;
-        const float s = pair_score<XF>(vol, o.L, o.n_t, o.tx + trx, o.ty + try_, o.W, o.H, h, act);
+        const float s = pair_score(vol, o.L, o.n_t, o.tx + trx, o.ty + try_, o.W, o.H, h, act);
         if (act && h == 0) o.sc[idx < 0 ? 2 * o.WIN : dst + idx] = s;
     }
 }
@@ -181,7 +171,6 @@ __device__ __forceinline__ void score_range(const float* __restrict__ vol, const
 // the rule.  IndulgentOptimize walks like DefaultOptimize (a passed-through score is scored again at the
 // same multiplier until the allowance is used up, then the walk breaks) but starts the negative direction
 // from the initial score again.
-template <bool XF>
 __device__ __forceinline__ void optimise(const float* __restrict__ vol, const OptState& o, float& best, long long& best_k,
                                          unsigned long long& n_eval) {
     const int WIN = o.WIN, B = o.B;
@@ -196,11 +185,11 @@ __device__ __forceinline__ void optimise(const float* __restrict__ vol, const Op
         const bool act = slot == 0 || is_p || is_n;
         const long long k = is_p ? 1 + idx : (is_n ? -1 - (idx - have_p) : 0);
         const float trx = slot == 0 ? 0.f : (float)k * o.savx, try_ = slot == 0 ? 0.f : (float)k * o.savy;
-        const float s = pair_score<XF>(vol, o.L, o.n_t, o.tx + trx, o.ty + try_, o.W, o.H, h, act);
+        const float s = pair_score(vol, o.L, o.n_t, o.tx + trx, o.ty + try_, o.W, o.H, h, act);
         if (act && h == 0) o.sc[slot == 0 ? 2 * WIN : (is_p ? idx : WIN + (idx - have_p))] = s;
     } else {
-        score_range<XF>(vol, o, +1, 1, have_p, 0, true);
-        score_range<XF>(vol, o, -1, -1, have_n, WIN, false);
+        score_range(vol, o, +1, 1, have_p, 0, true);
+        score_range(vol, o, -1, -1, have_n, WIN, false);
     }
     const float init = o.sc[2 * WIN];
     n_eval += 1;
@@ -224,7 +213,7 @@ __device__ __forceinline__ void optimise(const float* __restrict__ vol, const Op
                     win0 = k0 + dir * c0;
                     const long long left = dir > 0 ? (lim - win0 + 1) : (win0 - lim + 1);
                     have = (int)min<long long>(WIN, left);
-                    score_range<XF>(vol, o, dir, win0, have, off, false);
+                    score_range(vol, o, dir, win0, have, off, false);
                     rel = 0;
                 }
                 const int take = (int)min<long long>(nb - c0, have - rel);
@@ -304,16 +293,14 @@ __device__ __forceinline__ void work_scan(int* bins, int* partial, int tid) {
     for (int q = 0; q < PER; ++q) bins[tid * PER + q] = excl + loc[q];
 }
 
-// REG: up to 16 slots per thread, kept in registers (all loads in flight at once, no second pass
-// over memory); otherwise the ranks go through slot_rank.
-template <bool REG>
-__global__ void __launch_bounds__(1024) k_worklist(const SearchParams P, long long n_slots, int2* __restrict__ work,
-                                                   int* __restrict__ slot_rank) {
+// Up to 16384 slots: one workgroup, 16 slots per thread kept in registers (all loads in flight at once, no second
+// pass over memory).
+__global__ void __launch_bounds__(1024) k_worklist(const SearchParams P, long long n_slots, int2* __restrict__ work) {
     __shared__ int bins[kWorkBins];
     __shared__ int partial[1024];
     const int tid = threadIdx.x, lane = tid & 63;
     for (int i = tid; i < kWorkBins; i += 1024) bins[i] = 0;
-    if (REG) {
+    {
         constexpr int RR = 16;
         int2 pr[RR];
         int rk[RR];
@@ -335,44 +322,69 @@ __global__ void __launch_bounds__(1024) k_worklist(const SearchParams P, long lo
             const int t = (int)(i / P.pairs_stride);
             work[bins[work_key(pr[r].y)] + rk[r]] = make_int2(t, (int)(i - (long long)t * P.pairs_stride));
         }
-        return;
+    }
+}
+
+// More than 16384 slots: the same counting sort over several workgroups.  Each block takes 16384 slots:
+//   k_wl_count    block-local histogram in LDS, one global atomicAdd per (block, non-empty bin)
+//   k_wl_starts   exclusive scan of the global histogram (one block) -> first index of every bin; cursors zeroed
+//   k_wl_scatter  block-local ranks again (same loads), one global atomicAdd per (block, non-empty bin) reserves the
+//                 block's range inside the bin; the order inside a bin is arbitrary, as in the one-block version
+static constexpr int kWlSlotsPerBlock = 16 * 1024;
+__global__ void __launch_bounds__(1024) k_wl_count(const SearchParams P, long long n_slots, int* __restrict__ ghist) {
+    __shared__ int bins[kWorkBins];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < kWorkBins; i += 1024) bins[i] = 0;
+    __syncthreads();
+    const long long b0 = (long long)blockIdx.x * kWlSlotsPerBlock;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const long long i = b0 + (long long)r * 1024 + tid;
+        const int2 pr = i < n_slots ? P.pairs[i] : make_int2(-1, -1);
+        if (pr.x >= 0) atomicAdd(&bins[work_key(pr.y)], 1);
     }
     __syncthreads();
-    // 16 slots per thread at a time, all loads of a batch in flight together
-    constexpr int RB = 16;
-    for (long long b0 = 0; b0 < n_slots; b0 += (long long)RB * 1024) {
-        int2 pr[RB];
-#pragma unroll
-        for (int r = 0; r < RB; ++r) {
-            const long long i = b0 + (long long)r * 1024 + tid;
-            pr[r] = i < n_slots ? P.pairs[i] : make_int2(-1, -1);
-        }
-#pragma unroll
-        for (int r = 0; r < RB; ++r) {
-            const long long i = b0 + (long long)r * 1024 + tid;
-            const int rank = work_rank(bins, work_key(pr[r].y), pr[r].x >= 0, lane);
-            if (pr[r].x >= 0) slot_rank[i] = rank;
-        }
-    }
+    for (int i = tid; i < kWorkBins; i += 1024)
+        if (bins[i]) atomicAdd(&ghist[i], bins[i]);
+}
+__global__ void __launch_bounds__(1024) k_wl_starts(int* __restrict__ ghist, int* __restrict__ cursor) {
+    __shared__ int bins[kWorkBins];
+    __shared__ int partial[1024];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < kWorkBins; i += 1024) { bins[i] = ghist[i]; cursor[i] = 0; }
     __syncthreads();
     work_scan(bins, partial, tid);
     __syncthreads();
-    for (long long b0 = 0; b0 < n_slots; b0 += (long long)RB * 1024) {  // scatter
-        int2 pr[RB];
-        int rk[RB];
+    for (int i = tid; i < kWorkBins; i += 1024) ghist[i] = bins[i];  // now the first index of every bin
+}
+__global__ void __launch_bounds__(1024) k_wl_scatter(const SearchParams P, long long n_slots, const int* __restrict__ starts,
+                                                     int* __restrict__ cursor, int2* __restrict__ work) {
+    __shared__ int bins[kWorkBins];   // local counts, then the block's first index inside each bin
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int i = tid; i < kWorkBins; i += 1024) bins[i] = 0;
+    __syncthreads();
+    const long long b0 = (long long)blockIdx.x * kWlSlotsPerBlock;
+    int2 pr[16];
+    int rk[16];
 #pragma unroll
-        for (int r = 0; r < RB; ++r) {
-            const long long i = b0 + (long long)r * 1024 + tid;
-            pr[r] = i < n_slots ? P.pairs[i] : make_int2(-1, -1);
-            rk[r] = i < n_slots ? slot_rank[i] : 0;
-        }
+    for (int r = 0; r < 16; ++r) {
+        const long long i = b0 + (long long)r * 1024 + tid;
+        pr[r] = i < n_slots ? P.pairs[i] : make_int2(-1, -1);
+    }
 #pragma unroll
-        for (int r = 0; r < RB; ++r) {
-            if (pr[r].x < 0) continue;
-            const long long i = b0 + (long long)r * 1024 + tid;
-            const int t = (int)(i / P.pairs_stride);
-            work[bins[work_key(pr[r].y)] + rk[r]] = make_int2(t, (int)(i - (long long)t * P.pairs_stride));
-        }
+    for (int r = 0; r < 16; ++r) rk[r] = work_rank(bins, work_key(pr[r].y), pr[r].x >= 0, lane);
+    __syncthreads();
+    for (int i = tid; i < kWorkBins; i += 1024) {
+        const int c = bins[i];
+        bins[i] = c ? starts[i] + atomicAdd(&cursor[i], c) : 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        if (pr[r].x < 0) continue;
+        const long long i = b0 + (long long)r * 1024 + tid;
+        const int t = (int)(i / P.pairs_stride);
+        work[bins[work_key(pr[r].y)] + rk[r]] = make_int2(t, (int)(i - (long long)t * P.pairs_stride));
     }
 }
 
@@ -459,7 +471,7 @@ __global__ void __launch_bounds__(256) k_search(const SearchParams P) {
         o.reset_back = P.optimizer == FDCM_INDULGENT_OPTIMIZE;
         // static_cast<long>(max_mul / min_mul), batchoptimize.cpp:51,74
         o.lim_p = (long long)max_mul; o.lim_n = (long long)min_mul;
-        optimise<false>(P.vol, o, best, best_k, n_eval);
+        optimise(P.vol, o, best, best_k, n_eval);
     }
     if (lane == 0) {
         fdcm_match r;
@@ -564,6 +576,15 @@ void run_search(fdcm_featuremap* fm, const fdcm_templates* t, const float* scene
     fm->last_search = fdcm_search_timing{};
     // early-outs of search<DefaultMatch>, defaultmatch.cpp:40-41
     if (t->T == 0 || n_scene == 0 || (fm->W == 0 && fm->H == 0)) return;
+    {
+        // The orientation bins of the aligned template lines come from the device restatement of glibc 2.35's atanf,
+        // the scene's from the host libm (as in the reference): on a host whose libm differs the two would
+        // silently disagree, so the first search checks a sample (every 65537th bit pattern, a few ms) and refuses.
+        static const int64_t libm_mismatches = fdcm_selftest_atanf(0, 65537, (1ull << 32) / 65537);
+        if (libm_mismatches != 0)
+            throw std::string("this host's libm atanf differs from the device restatement (glibc 2.35 fdlibm) on ") +
+                std::to_string(libm_mismatches) + " sampled inputs: orientation bins would not match the reference's";
+    }
     FDCM_HIP(hipSetDevice(fm->device));
     if (!fm->stream) FDCM_HIP(hipStreamCreateWithFlags(&fm->stream, hipStreamNonBlocking));
     if (!fm->timing.created) {
@@ -642,7 +663,8 @@ void run_search(fdcm_featuremap* fm, const fdcm_templates* t, const float* scene
     P.cand_offsets = (const long long*)(ds + o_coff);
     P.bpt = (int)((cpt_max + kWavesPerBlock - 1) / kWavesPerBlock);
     P.ncand = ncand;
-    P.xcd_parts = getenv("FDCM_SEARCH_XCD_PARTS") ? atoi(getenv("FDCM_SEARCH_XCD_PARTS")) : 0;
+    static const int env_xcd_parts = getenv("FDCM_SEARCH_XCD_PARTS") ? atoi(getenv("FDCM_SEARCH_XCD_PARTS")) : 0;  // tuning override, read once
+    P.xcd_parts = env_xcd_parts;
     P.lds_lines = (int)std::max<int64_t>(1, t->max_lines);
     P.records = fm->s_records.as<fdcm_match>();
     P.flags = fm->s_flags.as<int>();
@@ -663,10 +685,18 @@ void run_search(fdcm_featuremap* fm, const fdcm_templates* t, const float* scene
     static const bool no_worklist = getenv("FDCM_SEARCH_TEMPLATE_MAJOR") != nullptr;  // tuning override
     if (!no_worklist && n_slots <= 0x7fffffffll) {
         const size_t work_bytes = ((size_t)(ncand / 2) * sizeof(int2) + 15) & ~(size_t)15;
-        fm->s_work.reserve(work_bytes + (size_t)n_slots * sizeof(int));
-        int* slot_rank = (int*)((char*)fm->s_work.p + work_bytes);
-        if (n_slots <= 16 * 1024) hipLaunchKernelGGL(k_worklist<true>, dim3(1), dim3(1024), 0, st, P, n_slots, fm->s_work.as<int2>(), slot_rank);
-        else hipLaunchKernelGGL(k_worklist<false>, dim3(1), dim3(1024), 0, st, P, n_slots, fm->s_work.as<int2>(), slot_rank);
+        fm->s_work.reserve(work_bytes + 2 * (size_t)kWorkBins * sizeof(int));
+        if (n_slots <= kWlSlotsPerBlock) {
+            hipLaunchKernelGGL(k_worklist, dim3(1), dim3(1024), 0, st, P, n_slots, fm->s_work.as<int2>());
+        } else {
+            int* ghist = (int*)((char*)fm->s_work.p + work_bytes);
+            int* cursor = ghist + kWorkBins;
+            const unsigned nb = (unsigned)((n_slots + kWlSlotsPerBlock - 1) / kWlSlotsPerBlock);
+            FDCM_HIP(hipMemsetAsync(ghist, 0, (size_t)kWorkBins * sizeof(int), st));
+            hipLaunchKernelGGL(k_wl_count, dim3(nb), dim3(1024), 0, st, P, n_slots, ghist);
+            hipLaunchKernelGGL(k_wl_starts, dim3(1), dim3(1024), 0, st, ghist, cursor);
+            hipLaunchKernelGGL(k_wl_scatter, dim3(nb), dim3(1024), 0, st, P, n_slots, ghist, cursor, fm->s_work.as<int2>());
+        }
         P.work = fm->s_work.as<int2>();
         P.nblocks = (int)(((ncand + kWavesPerBlock - 1) / kWavesPerBlock + 7) / 8 * 8);
     } else {
