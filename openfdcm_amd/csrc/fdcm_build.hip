@@ -906,7 +906,8 @@ __global__ void __launch_bounds__(256) k_fill(float* __restrict__ vol, int W, in
             f_pk[e][tid] = pk[e]; f_b[e][tid] = bb[e];
         }
         const int lim = (int)(pk[RE - 1] >> 16);
-        const int qstop = min(qend, __builtin_amdgcn_readfirstlane(wave_min(lim)));
+        // (max: the lists k_addend writes always allow progress; never spin on anything else)
+        const int qstop = max(qcur + 1, min(qend, __builtin_amdgcn_readfirstlane(wave_min(lim))));
         unsigned cpk = pk[0], npk = pk[1];
         float cb = bb[0], nb = bb[1];
         int a = 0;
