@@ -505,11 +505,11 @@ __device__ __forceinline__ void desc_lane4(const uint4& d, int j, unsigned long 
     nc = __builtin_amdgcn_readlane((int)d.w, j);
 }
 
-template <int C, int NT, int GW, bool DBG>
-__global__ void __launch_bounds__(NT) k_env(const ColDesc* __restrict__ desc, int W, int H, int HW64, int S, K2Buf B, int expm) {
-    __shared__ unsigned long long smask[256];  // seeded columns of the slice, 64 per word (W <= 16384)
-    __shared__ int cj[NT / 64 + 1][64];        // junction column of segment w per row
-    __shared__ float4 ring[C][NT];             // stack entries below the top: (float(v), f[v], z, float(v)^2)
+// Phase 1 of k_sweep.  smask: seeded columns of the slice, 64 per word (W <= 16384); cj: junction column of
+// segment w per row; ring: stack entries below the top, (float(v), f[v], z, float(v)^2), C per thread.
+template <int C, int NT, bool DBG>
+__device__ __forceinline__ void env_phase(const ColDesc* __restrict__ desc, int W, int H, int HW64, int S, const K2Buf& B,
+                                          int expm, unsigned long long* smask, int (*cj)[64], float4 (*ring)[NT]) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const long chunk = blockIdx.x;
     const long k = chunk / HW64;
@@ -727,15 +727,11 @@ __global__ void __launch_bounds__(NT) k_env(const ColDesc* __restrict__ desc, in
 // previous segment's top).  Every lane streams through its own row; the entries of a batch are staged in LDS so
 // that one compact loop body serves every entry; the owner entries collect in an LDS ring and go to HBM in
 // bursts, so that the loads of the walk do not queue behind stores.
-template <int KL, bool DBG>
-__global__ void __launch_bounds__(64) k_addend(int W, int S, int part_w, K2Buf B, int force_mod) {
-    constexpr int NB = 16;                // entries per batch
-    __shared__ unsigned l_pk[KL][64];     // the last KL owner entries of each row
-    __shared__ float l_b[KL][64];
-    __shared__ int e_v[NB][64];           // the batch being walked
-    __shared__ float e_f[NB][64];
-    __shared__ float e_z[NB][64];
-    const int lane = threadIdx.x;
+template <int KL, int NB, bool DBG>
+__device__ __forceinline__ void addend_phase(int W, int S, int part_w, const K2Buf& B, int force_mod, unsigned (*l_pk)[64],
+                                             float (*l_b)[64], int (*e_v)[64], float (*e_f)[64], float (*e_z)[64]) {
+    // l_pk / l_b: the last KL owner entries of each row; e_*: the batch (NB entries) being walked
+    const int lane = threadIdx.x & 63;
     const long chunk = blockIdx.x;
     const size_t NR = (size_t)B.NR;
     const size_t r = (size_t)chunk * 64 + lane;
@@ -872,10 +868,9 @@ __global__ void __launch_bounds__(64) k_addend(int W, int S, int part_w, K2Buf B
 // Pure fill (imgproc.h:122-128) from the owner list; wave p of a block fills the pixels
 // [p * part_w, (p + 1) * part_w) of the block's 64 rows, writes to column q are coalesced.
 template <int RE>
-__global__ void __launch_bounds__(256) k_fill(float* __restrict__ vol, int W, int H, int HW64, int part_w, K2Buf B) {
-    __shared__ unsigned f_pk[RE][256];
-    __shared__ float f_b[RE][256];
-    const int tid = threadIdx.x, lane = tid & 63, p = __builtin_amdgcn_readfirstlane(tid >> 6);
+__device__ __forceinline__ void fill_phase(float* __restrict__ vol, int W, int H, int HW64, int part_w, const K2Buf& B, int p,
+                                           unsigned (*f_pk)[256], float (*f_b)[256]) {
+    const int tid = threadIdx.x & 255, lane = tid & 63;
     const long chunk = blockIdx.x;
     const long k = chunk / HW64;
     const int c = (int)(chunk - k * HW64);
@@ -884,7 +879,7 @@ __global__ void __launch_bounds__(256) k_fill(float* __restrict__ vol, int W, in
     const size_t r = (size_t)chunk * 64 + lane;
     int qcur = p * part_w;
     const int qend = min(qcur + part_w, W);
-    if (qcur >= qend) return;
+    if (qcur >= qend) return;  // (last phase of the kernel: nothing waits for this wave any more)
     int idx = p == 0 ? 0 : B.partidx[(size_t)(p - 1) * NR + r];
     const int lc = B.lcount[r];
     const OwnEntry* own = B.own + r * (size_t)B.lslots;
@@ -920,6 +915,40 @@ __global__ void __launch_bounds__(256) k_fill(float* __restrict__ vol, int W, in
         }
         idx += a;
         qcur = qstop;
+    }
+}
+
+// The three phases in one launch, one workgroup per 64-row chunk: the chunks whose construction is long (rows far
+// from every seed: long gaps without an envelope vertex) are not the ones whose owner lists are long (rows along a
+// scene line), so running addend and fill of a chunk right behind its own construction lets the tails of the phases
+// overlap between chunks instead of adding up between launches (config 2: 0.54 -> measured in DESIGN.md).  The LDS
+// of the construction's ring is reused by the later phases.
+template <int C, int NT, bool DBG>
+__global__ void __launch_bounds__(NT) k_sweep(const ColDesc* __restrict__ desc, float* __restrict__ vol, int W, int H, int HW64,
+                                              int S, int part_w, K2Buf B, int force_mod, int expm) {
+    constexpr int KL = 64, NB = 16, RE = 16;
+    static_assert((size_t)C * NT * sizeof(float4) >= (size_t)(2 * KL + 3 * NB) * 64 * 4, "ring too small for the addend phase");
+    static_assert((size_t)C * NT * sizeof(float4) >= (size_t)2 * RE * 256 * 4, "ring too small for the fill phase");
+    __shared__ unsigned long long smask[256];
+    __shared__ int cj[NT / 64 + 1][64];
+    __shared__ float4 pool[C * NT];
+    env_phase<C, NT, DBG>(desc, W, H, HW64, S, B, expm, smask, cj, reinterpret_cast<float4(*)[NT]>(pool));
+    __syncthreads();  // every segment's stack, count and minF are in memory
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    if (wave == 0) {
+        unsigned* w32 = reinterpret_cast<unsigned*>(pool);
+        addend_phase<KL, NB, DBG>(W, S, part_w, B, force_mod, reinterpret_cast<unsigned(*)[64]>(w32),
+                                  reinterpret_cast<float(*)[64]>(w32 + KL * 64), reinterpret_cast<int(*)[64]>(w32 + 2 * KL * 64),
+                                  reinterpret_cast<float(*)[64]>(w32 + (2 * KL + NB) * 64),
+                                  reinterpret_cast<float(*)[64]>(w32 + (2 * KL + 2 * NB) * 64));
+    }
+    __syncthreads();  // the chunk's owner lists are in memory
+    {
+        unsigned* w32 = reinterpret_cast<unsigned*>(pool);
+        const int nw = (int)blockDim.x >> 6;
+        for (int p = wave; p < kFillParts; p += nw)
+            fill_phase<RE>(vol, W, H, HW64, part_w, B, p, reinterpret_cast<unsigned(*)[256]>(w32),
+                           reinterpret_cast<float(*)[256]>(w32 + RE * 256));
     }
 }
 
@@ -1301,10 +1330,10 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after) {
     static const int env_force_redo = getenv("FDCM_K2_FORCE_REDO") ? atoi(getenv("FDCM_K2_FORCE_REDO")) : 0;
     static const bool env_debug = getenv("FDCM_K2_DEBUG") != nullptr;  // per-wave clock stamps, printed after the sweep
     static const int env_experiment = getenv("FDCM_K2_EXPERIMENT") ? atoi(getenv("FDCM_K2_EXPERIMENT")) : 0;  // debug kernels only
-    // The segmented sweep wins where the one-wave-per-chunk kernel cannot fill the chip (config 2: 480 chunks, 0.54 vs
-    // 0.65 ms); on large volumes both are bound by the same per-column chain and the fused kernel has less overhead
-    // (config 3: 1920 chunks, 1.79 vs 2.08 ms).  FDCM_K2_SEGMENTS forces the segmented path at any size.
-    const bool segmented = fm->distance != FDCM_L1 && !env_legacy && (nchunks <= 1024 || env_segments > 0);
+    // The segmented sweep (k_sweep) is the default: config 2 (480 chunks) 0.47 ms against 0.65 ms for the
+    // one-wave-per-chunk kernel, config 3 (1920 chunks) 1.75 against 1.79 ms.  Its scratch is 20 B per pixel against
+    // 12 B, so volumes above 2^32 pixels (48 GB of scratch) keep the fused kernel.
+    const bool segmented = fm->distance != FDCM_L1 && !env_legacy && (nvox <= (1ull << 32) || env_segments > 0);
     int R = 64;                            // rows per wave of the one-wave-per-chunk L2 sweep: keep >= 2048 waves in flight
     if (!segmented) {
         while (R > 16 && nchunks * (64 / R) < 2048) R >>= 1;
@@ -1391,15 +1420,12 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after) {
             const int* gate = nullptr;
 #define FDCM_K2(RR, CC, SS, PP) hipLaunchKernelGGL((k_pass2_l2<RR, CC, SS, PP>), dim3(wblocks), dim3(256), 0, st, d_desc, vol, W, H, HW64, nwaves, sv, sf, sz, gate)
             if (segmented) {
-                // up to 4 segments: 256-thread blocks, 16-entry ring, two words of descriptors staged at a time;
-                // up to 8: 512-thread blocks with an 8-entry ring and one word (both ~75 KB of LDS: two blocks per CU)
-#define FDCM_ENV(CC, NN, GG, DD) hipLaunchKernelGGL((k_env<CC, NN, GG, DD>), dim3((unsigned)nchunks), dim3(64 * S), 0, st, d_desc, W, H, HW64, S, kb, env_experiment)
-                if (S <= 4) { if (env_debug) FDCM_ENV(16, 256, 2, true); else FDCM_ENV(16, 256, 2, false); }
-                else { if (env_debug) FDCM_ENV(8, 512, 1, true); else FDCM_ENV(8, 512, 1, false); }
-#undef FDCM_ENV
-                if (env_debug) hipLaunchKernelGGL((k_addend<64, true>), dim3((unsigned)nchunks), dim3(64), 0, st, W, S, part_w, kb, env_force_redo);
-                else hipLaunchKernelGGL((k_addend<64, false>), dim3((unsigned)nchunks), dim3(64), 0, st, W, S, part_w, kb, env_force_redo);
-                hipLaunchKernelGGL(k_fill<16>, dim3((unsigned)nchunks), dim3(256), 0, st, vol, W, H, HW64, part_w, kb);
+                // up to 4 segments: 256-thread blocks with a 16-entry ring; up to 8: 512-thread blocks with an 8-entry ring
+                // (both 64 KB of ring + 3 KB: two blocks per CU)
+#define FDCM_SWEEP(CC, NN, DD) hipLaunchKernelGGL((k_sweep<CC, NN, DD>), dim3((unsigned)nchunks), dim3(64 * S), 0, st, d_desc, vol, W, H, HW64, S, part_w, kb, env_force_redo, env_experiment)
+                if (S <= 4) { if (env_debug) FDCM_SWEEP(16, 256, true); else FDCM_SWEEP(16, 256, false); }
+                else { if (env_debug) FDCM_SWEEP(8, 512, true); else FDCM_SWEEP(8, 512, false); }
+#undef FDCM_SWEEP
                 // chunks whose junction check failed are redone literally, one wave per chunk (all others exit at once)
                 gate = kb.flags;
                 FDCM_K2(64, 8, 4, false);
