@@ -105,7 +105,6 @@ struct fdcm_featuremap {
     std::vector<float> keys;
     // device state
     fdcm::DevBuf vol;      // m*W*H float, [k][x][y]
-    fdcm::DevBuf tvol;     // optional copy of the volume in 4 x 4 tiles for the search's gathers
     fdcm::DevBuf bitmap;   // m*W*ceil(H/64) uint64 seed bits along y
     fdcm::DevBuf coldesc;  // m*ceil(H/64)*W column-chunk descriptors (16 B)
     fdcm::DevBuf offtab;   // m * max(W,H) chain offsets of the line integral

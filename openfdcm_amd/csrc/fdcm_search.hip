@@ -30,8 +30,7 @@ namespace fdcm {
 
 struct SearchParams {
     // feature map
-    const float* vol;    // [k][x][y], or the 4 x 4 tiled copy when TX > 0
-    int TX, TY;          // tiles per slice along x / y (0: plain layout)
+    const float* vol;    // [k][x][y]
     const float* keys;
     int W, H, m;
     float tx, ty;
@@ -82,21 +81,12 @@ __device__ __forceinline__ float wave_max_f(float v) {
 
 // evaluate<Dt3Cpu> for one line and one translation, dt3cpu.cpp:153-173.  L = per-wave LDS lines
 // (x1,y1,x2,y2,bin), off = sceneTranslation + translation.
-template <bool TILED>
 __device__ __forceinline__ float line_value(const float* __restrict__ vol, const float* L, int i, float offx,
                                             float offy, size_t W, size_t H) {
     const float* l = L + 5 * i;
     const int x1 = (int)(l[0] + offx), y1 = (int)(l[1] + offy);  // translate then cast<int>()
     const int x2 = (int)(l[2] + offx), y2 = (int)(l[3] + offy);
     const size_t bin = (size_t)__float_as_int(l[4]);
-    if (TILED) {
-        // 4 x 4 tiles of 64 B (y fastest inside a tile, tiles ordered [k][x / 4][y / 4]): the 32 translations of a gather
-        // round step along the scene line, so they fall into ~8 sectors whatever its direction, instead of 32 columns
-        const size_t TXs = W, TYs = H;  // the caller passes the tile counts in W / H
-        const size_t ia = ((bin * TXs + (size_t)(x1 >> 2)) * TYs + (size_t)(y1 >> 2)) * 16 + (size_t)(((x1 & 3) << 2) | (y1 & 3));
-        const size_t ib = ((bin * TXs + (size_t)(x2 >> 2)) * TYs + (size_t)(y2 >> 2)) * 16 + (size_t)(((x2 & 3) << 2) | (y2 & 3));
-        return f_abs(vol[ia] - vol[ib]);
-    }
     const float a = vol[(bin * W + (size_t)x1) * H + (size_t)y1];
     const float b = vol[(bin * W + (size_t)x2) * H + (size_t)y2];
     return f_abs(a - b);
@@ -106,7 +96,6 @@ __device__ __forceinline__ float line_value(const float* __restrict__ vol, const
 // Packet4f): p0 = packet(0), p1 = packet(4); blocks of 8: p0 += packet(i), p1 += packet(i+4);
 // p0 += p1; optional trailing packet; predux (p0+p2)+(p1+p3); scalar tail in order.
 // Lane h = 0 owns p0, lane h = 1 owns p1 of the same translation; the result is valid in h = 0.
-template <bool TILED>
 __device__ __forceinline__ float pair_score(const float* __restrict__ vol, const float* L, int n, float offx,
                                             float offy, size_t W, size_t H, int h, bool active) {
     const int aligned2 = (n / 8) * 8, aligned = (n / 4) * 4;
@@ -119,13 +108,13 @@ __device__ __forceinline__ float pair_score(const float* __restrict__ vol, const
                 const int b = 8 * i + 4 * h;
                 float v[4];
 #pragma unroll
-                for (int l = 0; l < 4; ++l) v[l] = line_value<TILED>(vol, L, b + l, offx, offy, W, H);
+                for (int l = 0; l < 4; ++l) v[l] = line_value(vol, L, b + l, offx, offy, W, H);
 #pragma unroll
                 for (int l = 0; l < 4; ++l) acc[l] = acc[l] + v[l];
             }
         } else if (aligned == 4 && h == 0) {
 #pragma unroll
-            for (int l = 0; l < 4; ++l) acc[l] = line_value<TILED>(vol, L, l, offx, offy, W, H);
+            for (int l = 0; l < 4; ++l) acc[l] = line_value(vol, L, l, offx, offy, W, H);
         }
     }
     float res = 0.f;
@@ -137,13 +126,13 @@ __device__ __forceinline__ float pair_score(const float* __restrict__ vol, const
         if (aligned) {
             if (aligned >= 8 && aligned > aligned2) {
 #pragma unroll
-                for (int l = 0; l < 4; ++l) acc[l] = acc[l] + line_value<TILED>(vol, L, aligned2 + l, offx, offy, W, H);
+                for (int l = 0; l < 4; ++l) acc[l] = acc[l] + line_value(vol, L, aligned2 + l, offx, offy, W, H);
             }
             res = (acc[0] + acc[2]) + (acc[1] + acc[3]);
-            for (int idx = aligned; idx < n; ++idx) res = res + line_value<TILED>(vol, L, idx, offx, offy, W, H);
+            for (int idx = aligned; idx < n; ++idx) res = res + line_value(vol, L, idx, offx, offy, W, H);
         } else if (n > 0) {
-            res = line_value<TILED>(vol, L, 0, offx, offy, W, H);
-            for (int idx = 1; idx < n; ++idx) res = res + line_value<TILED>(vol, L, idx, offx, offy, W, H);
+            res = line_value(vol, L, 0, offx, offy, W, H);
+            for (int idx = 1; idx < n; ++idx) res = res + line_value(vol, L, idx, offx, offy, W, H);
         }
     }
     return res;
@@ -162,7 +151,6 @@ struct OptState {
 
 // Score multipliers k_from, k_from + dir, ... (cnt of them) into sc[dst ..]; with_zero additionally
 // scores translation (0,0) into sc[2 WIN].  32 translations per gather round.
-template <bool TILED>
 __device__ __forceinline__ void score_range(const float* __restrict__ vol, const OptState& o, int dir, long long k_from,
                                             int cnt, int dst, bool with_zero) {
     const int h = o.lane >> 5, slot = o.lane & 31;  // neighbouring lanes = neighbouring translations
@@ -173,7 +161,7 @@ __device__ __forceinline__ void score_range(const float* __restrict__ vol, const
         const long long k = idx < 0 ? 0 : k_from + (long long)dir * idx;
         // translation = float(k) * scaled_align_vec (:58/:81); Point2{0,0} for the initial score (:36)
         const float trx = idx < 0 ? 0.f : (float)k * o.savx, try_ = idx < 0 ? 0.f : (float)k * o.savy;
-        const float s = pair_score<TILED>(vol, o.L, o.n_t, o.tx + trx, o.ty + try_, o.W, o.H, h, act);
+        const float s = pair_score(vol, o.L, o.n_t, o.tx + trx, o.ty + try_, o.W, o.H, h, act);
         if (act && h == 0) o.sc[idx < 0 ? 2 * o.WIN : dst + idx] = s;
     }
 }
@@ -183,7 +171,6 @@ __device__ __forceinline__ void score_range(const float* __restrict__ vol, const
 // the rule.  IndulgentOptimize walks like DefaultOptimize (a passed-through score is scored again at the
 // same multiplier until the allowance is used up, then the walk breaks) but starts the negative direction
 // from the initial score again.
-template <bool TILED>
 __device__ __forceinline__ void optimise(const float* __restrict__ vol, const OptState& o, float& best, long long& best_k,
                                          unsigned long long& n_eval) {
     const int WIN = o.WIN, B = o.B;
@@ -198,11 +185,11 @@ __device__ __forceinline__ void optimise(const float* __restrict__ vol, const Op
         const bool act = slot == 0 || is_p || is_n;
         const long long k = is_p ? 1 + idx : (is_n ? -1 - (idx - have_p) : 0);
         const float trx = slot == 0 ? 0.f : (float)k * o.savx, try_ = slot == 0 ? 0.f : (float)k * o.savy;
-        const float s = pair_score<TILED>(vol, o.L, o.n_t, o.tx + trx, o.ty + try_, o.W, o.H, h, act);
+        const float s = pair_score(vol, o.L, o.n_t, o.tx + trx, o.ty + try_, o.W, o.H, h, act);
         if (act && h == 0) o.sc[slot == 0 ? 2 * WIN : (is_p ? idx : WIN + (idx - have_p))] = s;
     } else {
-        score_range<TILED>(vol, o, +1, 1, have_p, 0, true);
-        score_range<TILED>(vol, o, -1, -1, have_n, WIN, false);
+        score_range(vol, o, +1, 1, have_p, 0, true);
+        score_range(vol, o, -1, -1, have_n, WIN, false);
     }
     const float init = o.sc[2 * WIN];
     n_eval += 1;
@@ -226,7 +213,7 @@ __device__ __forceinline__ void optimise(const float* __restrict__ vol, const Op
                     win0 = k0 + dir * c0;
                     const long long left = dir > 0 ? (lim - win0 + 1) : (win0 - lim + 1);
                     have = (int)min<long long>(WIN, left);
-                    score_range<TILED>(vol, o, dir, win0, have, off, false);
+                    score_range(vol, o, dir, win0, have, off, false);
                     rel = 0;
                 }
                 const int take = (int)min<long long>(nb - c0, have - rel);
@@ -401,7 +388,6 @@ __global__ void __launch_bounds__(1024) k_wl_scatter(const SearchParams P, long 
     }
 }
 
-template <bool TILED>
 __global__ void __launch_bounds__(256) k_search(const SearchParams P) {
     extern __shared__ float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -479,14 +465,13 @@ __global__ void __launch_bounds__(256) k_search(const SearchParams P) {
     unsigned long long n_eval = 0;
     if (valid) {
         OptState o;
-        o.L = L; o.sc = sc; o.n_t = n_t; o.tx = P.tx; o.ty = P.ty;
-        o.W = TILED ? (size_t)P.TX : (size_t)P.W; o.H = TILED ? (size_t)P.TY : (size_t)P.H;
+        o.L = L; o.sc = sc; o.n_t = n_t; o.W = (size_t)P.W; o.H = (size_t)P.H; o.tx = P.tx; o.ty = P.ty;
         o.savx = savx; o.savy = savy; o.lane = lane;
         o.B = P.optimizer == FDCM_BATCH_OPTIMIZE ? P.batch : 1; o.WIN = P.win; o.batch_rule = P.optimizer == FDCM_BATCH_OPTIMIZE;
         o.reset_back = P.optimizer == FDCM_INDULGENT_OPTIMIZE;
         // static_cast<long>(max_mul / min_mul), batchoptimize.cpp:51,74
         o.lim_p = (long long)max_mul; o.lim_n = (long long)min_mul;
-        optimise<TILED>(P.vol, o, best, best_k, n_eval);
+        optimise(P.vol, o, best, best_k, n_eval);
     }
     if (lane == 0) {
         fdcm_match r;
@@ -502,31 +487,6 @@ __global__ void __launch_bounds__(256) k_search(const SearchParams P) {
         // translations the reference's rule evaluated (reduced by the compaction kernels: one
         // contended atomic per candidate would serialise the whole grid at ~12 ns each)
         P.evals[cand] = (int)n_eval;
-    }
-}
-
-// [k][x][y] -> 4 x 4 tiles: one thread per tile, threads along y (reads 16 B per column, coalesced along y; writes
-// 64 B per thread, contiguous across the wave).  Elements past the image in edge tiles are never read by the search.
-__global__ void __launch_bounds__(256) k_tile(const float* __restrict__ vol, float* __restrict__ tvol, int W, int H, int TX, int TY) {
-    const int ty = blockIdx.x * 256 + threadIdx.x, tx = blockIdx.y, k = blockIdx.z;
-    if (ty >= TY) return;
-    const float* src = vol + ((size_t)k * W + (size_t)tx * 4) * H + (size_t)ty * 4;
-    float4* dst = reinterpret_cast<float4*>(tvol + (((size_t)k * TX + tx) * TY + ty) * 16);
-    const bool full_y = ty * 4 + 3 < H;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (tx * 4 + c < W) {
-            const float* col = src + (size_t)c * H;
-            if (full_y && (H & 3) == 0) v = *reinterpret_cast<const float4*>(col);
-            else {
-                v.x = col[0];
-                if (ty * 4 + 1 < H) v.y = col[1];
-                if (ty * 4 + 2 < H) v.z = col[2];
-                if (ty * 4 + 3 < H) v.w = col[3];
-            }
-        }
-        dst[c] = v;
     }
 }
 
@@ -679,14 +639,7 @@ void run_search(fdcm_featuremap* fm, const fdcm_templates* t, const float* scene
     fm->s_counter.reserve(64);
     // keys live at the end of the build plan blob; for adopted volumes they are uploaded there too
     SearchParams P{};
-    static const bool env_tiled = getenv("FDCM_SEARCH_TILED") != nullptr;  // experiment: score from a 4 x 4 tiled copy
     P.vol = fm->vol.as<float>();
-    P.TX = P.TY = 0;
-    if (env_tiled) {
-        P.TX = (int)((fm->W + 3) / 4); P.TY = (int)((fm->H + 3) / 4);
-        fm->tvol.reserve((size_t)fm->m * P.TX * P.TY * 16 * sizeof(float));
-        P.vol = fm->tvol.as<float>();
-    }
     P.keys = (const float*)((const char*)fm->plan.p + fm->off_keys);
     P.W = (int)fm->W; P.H = (int)fm->H; P.m = (int)fm->m; P.tx = fm->tx; P.ty = fm->ty;
     P.tlines = t->d_lines.as<float>();
@@ -724,10 +677,7 @@ void run_search(fdcm_featuremap* fm, const fdcm_templates* t, const float* scene
     const size_t lds = lds_floats * sizeof(float);
     if (lds > 160 * 1024) throw std::string("scene/template too large for the search kernel's LDS staging");
     if (lds > 64 * 1024)
-        {
-        FDCM_HIP(hipFuncSetAttribute((const void*)k_search<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        FDCM_HIP(hipFuncSetAttribute((const void*)k_search<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    }
+        FDCM_HIP(hipFuncSetAttribute((const void*)k_search, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t* ev = fm->timing.ev;
     FDCM_HIP(hipEventRecord(ev[6], st));
     hipLaunchKernelGGL(k_pairs, dim3((unsigned)(((size_t)t->T * maxT + 255) / 256)), dim3(256), 0, st, P);
@@ -753,13 +703,7 @@ void run_search(fdcm_featuremap* fm, const fdcm_templates* t, const float* scene
         P.work = nullptr;
         P.nblocks = (int)((size_t)t->T * P.bpt);
     }
-    if (P.TX) {
-        hipLaunchKernelGGL(k_tile, dim3((unsigned)((P.TY + 255) / 256), (unsigned)P.TX, (unsigned)fm->m), dim3(256), 0, st,
-                           fm->vol.as<float>(), fm->tvol.as<float>(), (int)fm->W, (int)fm->H, P.TX, P.TY);
-        hipLaunchKernelGGL(k_search<true>, dim3((unsigned)P.nblocks), dim3(256), lds, st, P);
-    } else {
-        hipLaunchKernelGGL(k_search<false>, dim3((unsigned)P.nblocks), dim3(256), lds, st, P);
-    }
+    hipLaunchKernelGGL(k_search, dim3((unsigned)P.nblocks), dim3(256), lds, st, P);
     fdcm_match* dst = out_device;
     if (!dst) {
         // host output: one extra record behind the candidates' capacity carries the counters, so that the
