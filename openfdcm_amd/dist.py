@@ -2,7 +2,8 @@
 
 Candidates of different templates are independent given the DT3 volume, so the template list is
 split into contiguous index ranges, every rank builds the (small-input) DT3 volume itself, and the
-only exchange is one gather of the 32-byte match records to rank 0.  Concatenating the shards in
+only exchange is one gather of the 32-byte match records to rank 0 (per frame: fixed-capacity blocks
+with the count in a trailing record, FrameGatherer).  Concatenating the shards in
 rank order reproduces the reference's positional order (defaultmatch.cpp:51-86) because the
 ranges are contiguous.  Backend "nccl" is RCCL on ROCm; "gloo" runs the same code on CPU tensors
 (used by the CPU tests with a stand-in search function).
@@ -113,39 +114,46 @@ def gather_topk(local_topk, k, device, group=None, dst=0):
 class FrameGatherer:
     """Persistent buffers for gathering one frame's match records per call (the per-frame path of the
     pipeline, where allocations, pageable copies and host-side concatenation would cost more than
-    the frame): one all_gather of the counts (one small sync), one gather of fixed-capacity blocks,
-    a device-side compaction and one pinned download.  Results are views into a ring of `depth` host
-    buffers: a returned array stays valid until `depth` more frames have been gathered."""
+    the frame).  ONE collective per frame: every rank sends a fixed-capacity block whose trailing
+    record carries its record count (the way fdcm_search hands matches and count to the host in one
+    copy), so no count exchange precedes the gather.  Rank `dst` then reads the counts out of the
+    gathered blocks (one small download), compacts on the device and downloads the exact list.
+    Results are views into a ring of `depth` host buffers: a returned array stays valid until
+    `depth` more frames have been gathered."""
 
     def __init__(self, capacity_records, device, group=None, dst=0, depth=4):
         self.group, self.dst, self.device = group, dst, device
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
-        self.blk = max(1, capacity_records) * RECORD_BYTES
+        self.cap = max(1, capacity_records)
+        self.blk = (self.cap + 1) * RECORD_BYTES  # records + the trailing count record
         cuda = device.type == "cuda"
-        self.count = torch.zeros(1, dtype=torch.int64, device=device)
-        self.counts = torch.zeros(self.world, dtype=torch.int64, device=device)
         self.counts_host = torch.zeros(self.world, dtype=torch.int64, pin_memory=cuda)
         if self.rank == dst:
             self.recv = torch.empty(self.world * self.blk, dtype=torch.uint8, device=device)
             self.recv_views = list(self.recv.split(self.blk))
-            self.packed = torch.empty(self.world * self.blk, dtype=torch.uint8, device=device)
-            self.host = [torch.empty(self.world * self.blk, dtype=torch.uint8, pin_memory=cuda) for _ in range(depth)]
+            # the count of rank r: first int64 of the trailing record of block r
+            self.trailers = self.recv.view(torch.int64).view(self.world, self.blk // 8)[:, self.cap * RECORD_BYTES // 8]
+            self.packed = torch.empty(self.world * self.cap * RECORD_BYTES, dtype=torch.uint8, device=device)
+            self.host = [torch.empty(self.world * self.cap * RECORD_BYTES, dtype=torch.uint8, pin_memory=cuda)
+                         for _ in range(depth)]
             self.turn = 0
 
+    def block_bytes(self):
+        return self.blk
+
     def gather(self, block, n_local):
-        """block: this rank's uint8 buffer of `blk` bytes whose first n_local records are valid."""
-        self.count.fill_(int(n_local))
-        dist.all_gather_into_tensor(self.counts, self.count, group=self.group)
-        self.counts_host.copy_(self.counts, non_blocking=True)
+        """block: this rank's uint8 buffer of block_bytes() bytes whose first n_local records are valid."""
+        block[: self.blk].view(torch.int64)[self.cap * RECORD_BYTES // 8] = int(n_local)  # queued on the caller's stream
         dist.gather(block[: self.blk], self.recv_views if self.rank == self.dst else None, dst=self.dst, group=self.group)
         if self.rank != self.dst:
             return None
+        self.counts_host.copy_(self.trailers, non_blocking=True)
         if self.device.type == "cuda":
-            torch.cuda.current_stream(self.device).synchronize()  # counts on the host (the gather is queued behind)
+            torch.cuda.current_stream(self.device).synchronize()  # counts on the host (the gather is queued before)
         counts = self.counts_host.tolist()
         total = sum(counts) * RECORD_BYTES
         off = 0
-        for r, c in enumerate(counts):  # compaction on the device: 8 slices, one contiguous list
+        for r, c in enumerate(counts):  # compaction on the device: one slice per rank, one contiguous list
             nb = c * RECORD_BYTES
             self.packed[off: off + nb].copy_(self.recv_views[r][:nb], non_blocking=True)
             off += nb
@@ -170,10 +178,9 @@ class ShardedPipeline:
         self.bufs = None
         self.gatherer = None
         if world_size > 1 if gather is None else gather:
-            # one record buffer per slot: ticket t runs on slot t % slots (include/fdcm.h)
-            self.bufs = [torch.empty(max(1, capacity_records) * RECORD_BYTES, dtype=torch.uint8, device=device)
-                         for _ in range(slots)]
+            # one record buffer per slot (capacity + the trailing count record): ticket t runs on slot t % slots
             self.gatherer = FrameGatherer(capacity_records, device, group=group, depth=slots + 2)
+            self.bufs = [torch.empty(self.gatherer.block_bytes(), dtype=torch.uint8, device=device) for _ in range(slots)]
         self.pending = []
         self.submitted = 0
         # per slot: event recorded (on torch's stream) behind the collective that reads the slot's record buffer

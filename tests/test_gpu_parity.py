@@ -594,3 +594,22 @@ def test_sharded_engine_rejects_bad_devices(amd):
         ShardedEngine(tmpls, devices=[0, 63])
     with pytest.raises(_capi.FdcmError, match="twice"):
         ShardedEngine(tmpls, devices=[0, 0])
+
+
+def test_bench_force_dist_runs_the_rccl_gather_and_passes_its_parity_gate(amd):
+    """bench.py --force-dist: the multi-process path (torch.distributed backend nccl = RCCL, per-frame gather with the
+    count in a trailing record, slot buffers guarded by events) with world size 1, frames in flight, checked by the
+    bench's own parity gate against the oracle."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29571", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--force-dist", "--steps", "8", "--warmup", "2",
+                          "--templates", "120", "--cpu-sample", "40", "--cpu-reps", "1", "--single-frames", "3"],
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+    doc = json.loads(out.stdout.strip().splitlines()[-1])
+    assert doc["parity_gate"] == "ok" and doc["n_gpus"] == 1 and doc["config"]["matches_per_step"] > 1000
+    assert doc["roofline"]["frac"] > 0 and doc["roofline_search"]["achieved"] > 0 and doc["cpu_baseline"]["cores"] >= 1
