@@ -207,7 +207,7 @@ def main():
     # feature map and workspaces on its first frame and runs a few more, so that the pipeline's streams, pinned
     # result buffers and clocks are in the state a running service has them in.
     fence()
-    run_frames(4 * F, False)
+    run_frames(int(os.environ.get("BENCH_SETUP_FRAMES", 4 * F)), False)
     run_frames(args.warmup, False)
     fence()
     t0 = time.perf_counter()

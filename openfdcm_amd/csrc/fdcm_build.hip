@@ -952,6 +952,31 @@ __global__ void __launch_bounds__(NT) k_sweep(const ColDesc* __restrict__ desc, 
     }
 }
 
+// The same phases as three launches: no wave waits at a barrier while one wave of its block runs the addend pass, so
+// the GPU's other work (frames of a pipeline) gets those slots; alone, the tails of the three launches add up.
+template <int C, int NT, bool DBG>
+__global__ void __launch_bounds__(NT) k_env(const ColDesc* __restrict__ desc, int W, int H, int HW64, int S, K2Buf B, int expm) {
+    __shared__ unsigned long long smask[256];
+    __shared__ int cj[NT / 64 + 1][64];
+    __shared__ float4 pool[C * NT];
+    env_phase<C, NT, DBG>(desc, W, H, HW64, S, B, expm, smask, cj, reinterpret_cast<float4(*)[NT]>(pool));
+}
+template <bool DBG>
+__global__ void __launch_bounds__(64) k_addend(int W, int S, int part_w, K2Buf B, int force_mod) {
+    constexpr int KL = 64, NB = 16;
+    __shared__ unsigned w32[(2 * KL + 3 * NB) * 64];
+    addend_phase<KL, NB, DBG>(W, S, part_w, B, force_mod, reinterpret_cast<unsigned(*)[64]>(w32),
+                              reinterpret_cast<float(*)[64]>(w32 + KL * 64), reinterpret_cast<int(*)[64]>(w32 + 2 * KL * 64),
+                              reinterpret_cast<float(*)[64]>(w32 + (2 * KL + NB) * 64),
+                              reinterpret_cast<float(*)[64]>(w32 + (2 * KL + 2 * NB) * 64));
+}
+__global__ void __launch_bounds__(256) k_fill(float* __restrict__ vol, int W, int H, int HW64, int part_w, K2Buf B) {
+    constexpr int RE = 16;
+    __shared__ unsigned w32[2 * RE * 256];
+    fill_phase<RE>(vol, W, H, HW64, part_w, B, __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6),
+                   reinterpret_cast<unsigned(*)[256]>(w32), reinterpret_cast<float(*)[256]>(w32 + RE * 256));
+}
+
 // distanceTransform<float, L1> (imgproc.h:176-181): the sweeps along y are the descriptor
 // distance (exact integers), the forward sweep along x runs on it directly (imgproc.h:138-140)
 // and writes V; the backward sweep (imgproc.h:142-145) reads that and writes the result in place.
@@ -1329,6 +1354,8 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after) {
     static const int env_segments = getenv("FDCM_K2_SEGMENTS") ? atoi(getenv("FDCM_K2_SEGMENTS")) : 0;
     static const int env_force_redo = getenv("FDCM_K2_FORCE_REDO") ? atoi(getenv("FDCM_K2_FORCE_REDO")) : 0;
     static const bool env_debug = getenv("FDCM_K2_DEBUG") != nullptr;  // per-wave clock stamps, printed after the sweep
+    static const bool env_unfused = getenv("FDCM_K2_UNFUSED") != nullptr;  // blocking builds: three launches instead of one
+    static const bool env_fused = getenv("FDCM_K2_FUSED") != nullptr;      // pipeline slots: one launch instead of three
     static const int env_experiment = getenv("FDCM_K2_EXPERIMENT") ? atoi(getenv("FDCM_K2_EXPERIMENT")) : 0;  // debug kernels only
     // The segmented sweep (k_sweep) is the default: config 2 (480 chunks) 0.47 ms against 0.65 ms for the
     // one-wave-per-chunk kernel, config 3 (1920 chunks) 1.75 against 1.79 ms.  Its scratch is 20 B per pixel against
@@ -1421,11 +1448,24 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after) {
 #define FDCM_K2(RR, CC, SS, PP) hipLaunchKernelGGL((k_pass2_l2<RR, CC, SS, PP>), dim3(wblocks), dim3(256), 0, st, d_desc, vol, W, H, HW64, nwaves, sv, sf, sz, gate)
             if (segmented) {
                 // up to 4 segments: 256-thread blocks with a 16-entry ring; up to 8: 512-thread blocks with an 8-entry ring
-                // (both 64 KB of ring + 3 KB: two blocks per CU)
+                // (both 64 KB of ring + 3 KB: two blocks per CU).  One launch for a blocking build (the phases' tails
+                // overlap between chunks), three for the slots of a frame pipeline (no wave idles at a barrier while the
+                // GPU has other frames' work).
+                const bool three = fm->throughput_mode ? !env_fused : env_unfused;
 #define FDCM_SWEEP(CC, NN, DD) hipLaunchKernelGGL((k_sweep<CC, NN, DD>), dim3((unsigned)nchunks), dim3(64 * S), 0, st, d_desc, vol, W, H, HW64, S, part_w, kb, env_force_redo, env_experiment)
-                if (S <= 4) { if (env_debug) FDCM_SWEEP(16, 256, true); else FDCM_SWEEP(16, 256, false); }
-                else { if (env_debug) FDCM_SWEEP(8, 512, true); else FDCM_SWEEP(8, 512, false); }
+#define FDCM_ENV(CC, NN, DD) hipLaunchKernelGGL((k_env<CC, NN, DD>), dim3((unsigned)nchunks), dim3(64 * S), 0, st, d_desc, W, H, HW64, S, kb, env_experiment)
+                if (!three) {
+                    if (S <= 4) { if (env_debug) FDCM_SWEEP(16, 256, true); else FDCM_SWEEP(16, 256, false); }
+                    else { if (env_debug) FDCM_SWEEP(8, 512, true); else FDCM_SWEEP(8, 512, false); }
+                } else {
+                    if (S <= 4) { if (env_debug) FDCM_ENV(16, 256, true); else FDCM_ENV(16, 256, false); }
+                    else { if (env_debug) FDCM_ENV(8, 512, true); else FDCM_ENV(8, 512, false); }
+                    if (env_debug) hipLaunchKernelGGL(k_addend<true>, dim3((unsigned)nchunks), dim3(64), 0, st, W, S, part_w, kb, env_force_redo);
+                    else hipLaunchKernelGGL(k_addend<false>, dim3((unsigned)nchunks), dim3(64), 0, st, W, S, part_w, kb, env_force_redo);
+                    hipLaunchKernelGGL(k_fill, dim3((unsigned)nchunks), dim3(256), 0, st, vol, W, H, HW64, part_w, kb);
+                }
 #undef FDCM_SWEEP
+#undef FDCM_ENV
                 // chunks whose junction check failed are redone literally, one wave per chunk (all others exit at once)
                 gate = kb.flags;
                 FDCM_K2(64, 8, 4, false);
