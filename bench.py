@@ -46,7 +46,7 @@ HBM_PEAK_GBS = 8000.0
 # V/16 of column descriptors and never materialises it); propagation reads V and writes V; line integral likewise.
 STAGE_BYTES_V = {"pass2_ms": 3.0, "propagate_ms": 2.0, "integral_ms": 2.0}
 STAGE_KERNELS = {"seeds_ms": "k_seeds", "pass1_ms": "k_coldesc",
-                 "pass2_ms": "L2 sweep: k_env + k_addend + k_fill (small volumes) / k_pass2_l2; L1: k_l1_forward + k_l1_backward",
+                 "pass2_ms": "L2 sweep: k_sweep (blocking) / k_env + k_addend + k_fill (pipeline slots); L1: k_l1_forward + k_l1_backward",
                  "propagate_ms": "k_propagate_reg", "integral_ms": "k_integral"}
 DIST_NAMES = {0: "L2", 1: "L2_SQUARED", 2: "L1"}
 # templates per GPU of the BASELINE configs (4 and 5 are sharded over 8 GPUs)
@@ -71,8 +71,8 @@ def pmc_traffic(config):
     if doc.get("so_sha256_16") != so_hash():
         return None, f"{os.path.basename(files[-1])} was measured on another build of libfdcm_hip.so"
     build = [v["hbm_bytes_per_launch"] * v.get("launches_per_frame", 1.0) for k, v in doc["kernels"].items()
-             if any(t in k for t in ("k_seeds", "k_coldesc", "k_env", "k_addend", "k_fill", "k_pass2", "k_l1", "k_propagate",
-                                     "k_integral"))]
+             # a blocking build: k_sweep, not the three-launch form the pipeline slots use (k_env, k_addend, k_fill)
+             if any(t in k for t in ("k_seeds", "k_coldesc", "k_sweep", "k_pass2", "k_l1", "k_propagate", "k_integral"))]
     return float(sum(build)), os.path.basename(files[-1])
 
 
