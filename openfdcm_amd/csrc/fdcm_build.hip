@@ -1313,9 +1313,10 @@ __device__ __forceinline__ void integral_steep(float* __restrict__ vol, int W, i
 // 256 chains and the surplus blocks of a shallow slice exit at once.
 __global__ void __launch_bounds__(256) k_integral(float* __restrict__ vol, int W, int H,
                                                   const IntegralDesc* __restrict__ desc,
-                                                  const int* __restrict__ offtab) {
+                                                  const int* __restrict__ offtab, int only_mode) {
     const int k = blockIdx.y;
     const IntegralDesc d = desc[k];
+    if (only_mode && d.mode != only_mode) return;  // timing experiment (FDCM_INT_ONLY): one kind of slice only
     if (d.mode == 1) integral_shallow(vol, W, H, d, k, offtab);
     else if (d.mode == 2) integral_steep<64>(vol, W, H, d, k);
 }
@@ -1566,7 +1567,8 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after) {
             hipLaunchKernelGGL(k_offsets, dim3((unsigned)((off_stride + 255) / 256), (unsigned)m), dim3(256), 0, st, d_int, d_off, (int)steps, off_stride);
             fm->off_m = m; fm->off_steps = steps;
         }
-        hipLaunchKernelGGL(k_integral, dim3((unsigned)((chains + 63) / 64), (unsigned)m), dim3(256), 0, st, vol, W, H, d_int, d_off);
+        static const int env_int_only = getenv("FDCM_INT_ONLY") ? atoi(getenv("FDCM_INT_ONLY")) : 0;  // timing experiment
+        hipLaunchKernelGGL(k_integral, dim3((unsigned)((chains + 63) / 64), (unsigned)m), dim3(256), 0, st, vol, W, H, d_int, d_off, env_int_only);
     }
     FDCM_HIP(hipEventRecord(ev[5], st));
     FDCM_HIP(hipGetLastError());
