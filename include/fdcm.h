@@ -97,7 +97,9 @@ int fdcm_featuremap_get_info(const fdcm_featuremap* fm, fdcm_featuremap_info* in
 int fdcm_featuremap_keys(const fdcm_featuremap* fm, float* keys /* depth floats, ascending */);
 /* Slice k as the reference stores it: RawImage<float>(H, W) column-major, (y,x) at x*H + y. */
 int fdcm_featuremap_slice(const fdcm_featuremap* fm, int64_t k, float* out_host);
-/* Whole volume [k][x][y] on the device (read-only view, valid until free/rebuild). */
+/* Whole volume on the device (read-only view, valid until free/rebuild).  Layout: 4 neighbouring x are
+ * interleaved so that a 64-byte sector holds 4 x by 4 y pixels (the search's gathers step about one pixel per
+ * translation in any direction): pixel (k, x, y) is element ((k * ceil(W/4) + x/4) * H + y) * 4 + x%4. */
 int fdcm_featuremap_device_volume(const fdcm_featuremap* fm, const float** device_ptr);
 int fdcm_featuremap_last_timing(const fdcm_featuremap* fm, fdcm_build_timing* t);
 /* Dt3Cpu(dt3map, sceneTranslation, featureSize) constructor (dt3cpu.h:55-58): adopt caller slices. */

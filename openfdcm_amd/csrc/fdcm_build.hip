@@ -1062,14 +1062,31 @@ __global__ void k_sqrt(float* __restrict__ vol, size_t n) {  // only for staged 
 // propagateOrientation (dt3cpu.cpp:77-107): each pixel's m-vector is loaded once into LDS
 // ([slice][thread], conflict free), the 4m steps S[c2] = min(S[c2], S[c1] + w) run there, and it
 // is stored once.  L2's final sqrt (imgproc.h:191-192) is applied on load.
-__global__ void k_propagate(float* __restrict__ vol, size_t npix, int m, const PropStep* __restrict__ steps,
-                            int nsteps, int apply_sqrt) {
+// Both variants read the y-fastest volume of the sweeps and write the interleaved volume (ivol_index) that the line
+// integral and the search work on.  A thread is a position of the interleaved slice, q = (g*H + y)*4 + c for pixel
+// (4g + c, y): 64 consecutive threads store 256 contiguous bytes and load 4 runs of 64 bytes (16 rows of 4 columns).
+struct PropPixel {
+    unsigned in_off, out_off;  // byte offsets inside a slice; 2^31: outside (columns of the last group past W)
+};
+__device__ __forceinline__ PropPixel prop_pixel(size_t q, int W, int H) {
+    const unsigned g = (unsigned)(q / ((size_t)H * 4)), r = (unsigned)(q % ((size_t)H * 4));
+    const unsigned y = r >> 2, x = 4 * g + (r & 3);
+    PropPixel pp;
+    pp.out_off = (unsigned)q * 4u;
+    pp.in_off = x < (unsigned)W ? (x * (unsigned)H + y) * 4u : 0x80000000u;
+    return pp;
+}
+
+__global__ void k_propagate(const float* __restrict__ vol, float* __restrict__ ivol, int W, int H, int m,
+                            const PropStep* __restrict__ steps, int nsteps, int apply_sqrt) {
     extern __shared__ float S[];
     const int bd = blockDim.x, tid = threadIdx.x;
-    const size_t p = (size_t)blockIdx.x * bd + tid;
-    const bool ok = p < npix;
+    const size_t q = (size_t)blockIdx.x * bd + tid, npix = (size_t)W * H, nq = ivol_slice_floats(W, H);
+    const bool ok = q < nq;
+    const PropPixel pp = prop_pixel(ok ? q : 0, W, H);
+    const bool in = ok && pp.in_off != 0x80000000u;
     for (int j = 0; j < m; ++j) {
-        float v = ok ? vol[(size_t)j * npix + p] : 0.f;
+        float v = in ? vol[(size_t)j * npix + pp.in_off / 4] : 0.f;
         if (apply_sqrt) v = sqrtf(v);
         S[j * bd + tid] = v;
     }
@@ -1080,26 +1097,26 @@ __global__ void k_propagate(float* __restrict__ vol, size_t npix, int m, const P
         S[st.c2 * bd + tid] = std_min(a, b);
     }
     if (ok)
-        for (int j = 0; j < m; ++j) vol[(size_t)j * npix + p] = S[j * bd + tid];
+        for (int j = 0; j < m; ++j) ivol[(size_t)j * nq + q] = S[j * bd + tid];
 }
 
 // Register-resident variant for the common depths: the ring indices of propagateOrientation's
 // 4M steps (dt3cpu.cpp:88-89) are compile-time constants, so the pixel's M-vector stays in VGPRs
 // and the kernel is a pure stream (read V, write V) at full occupancy.
 template <int M>
-__global__ void __launch_bounds__(256) k_propagate_reg(float* __restrict__ vol, size_t npix,
+__global__ void __launch_bounds__(256) k_propagate_reg(const float* __restrict__ vol, float* __restrict__ ivol, int W, int H,
                                                        const PropStep* __restrict__ steps, int apply_sqrt) {
-    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= npix) return;
+    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x, npix = (size_t)W * H, nq = ivol_slice_floats(W, H);
+    if (q >= nq) return;
     // One buffer descriptor per slice (scalar registers) + one 32-bit lane byte offset: addresses
     // cost no vector registers, so the M values are the kernel's whole register footprint.
-    const int boff = (int)((unsigned)p * 4u);  // npix < 2^30
-    const unsigned slice_bytes = (unsigned)(npix * 4u);
+    const PropPixel pp = prop_pixel(q, W, H);  // slices are < 2^30 pixels
+    const unsigned in_bytes = (unsigned)(npix * 4u), out_bytes = (unsigned)(nq * 4u);
     float S[M];
 #pragma unroll
     for (int j = 0; j < M; ++j) {
-        const auto rs = __builtin_amdgcn_make_buffer_rsrc(vol + (size_t)j * npix, 0, slice_bytes, 0x00020000);
-        S[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, boff, 0, 0));
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(vol) + (size_t)j * npix, 0, in_bytes, 0x00020000);
+        S[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, pp.in_off, 0, 0));
     }
     if (apply_sqrt) {
 #pragma unroll
@@ -1110,7 +1127,6 @@ __global__ void __launch_bounds__(256) k_propagate_reg(float* __restrict__ vol, 
     int s = 0;
 #pragma unroll
     for (int c = 0; c < FWD; ++c, ++s) {  // propagate(0, ceil(1.5 m), +1)
-        constexpr int dummy = 0; (void)dummy;
         const int c1 = (M + ((c - 1) % M)) % M, c2 = (M + (c % M)) % M;
         S[c2] = std_min(S[c2], S[c1] + steps[s].w);
     }
@@ -1122,153 +1138,197 @@ __global__ void __launch_bounds__(256) k_propagate_reg(float* __restrict__ vol, 
     }
 #pragma unroll
     for (int j = 0; j < M; ++j) {
-        const auto rs = __builtin_amdgcn_make_buffer_rsrc(vol + (size_t)j * npix, 0, slice_bytes, 0x00020000);
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(S[j]), rs, boff, 0, 0);
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(ivol + (size_t)j * nq, 0, out_bytes, 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(S[j]), rs, pp.out_off, 0, 0);
     }
 }
 
 // ------------------------------------------------------------------------------------------ K4
 // lineIntegral (imgproc.h:38-84).  The reference adds the previous (already integrated) line,
 // shifted by dy_i = round(i r) - round((i-1) r), into the current one; the shifts telescope, so
-// pixel (x_i, c + round(i r)) belongs to chain c and each chain is one sequential float32 sum.
-// One thread per chain; the order of additions is the reference's.
-// Chain offsets round(float(i) * r) of every slice (imgproc.h:54-55,70-71), one table row per slice.
-__global__ void k_offsets(const IntegralDesc* __restrict__ desc, int* __restrict__ offtab, int steps, int stride) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
-    // byte offsets; the padding past the last step holds 2^31 + 4*steps, which stays >= 2^31 after any chain
-    // origin in [-steps, steps) is added: out of range for the buffer unit
-    if (i < stride)
-        offtab[(size_t)k * stride + i] = i < steps ? 4 * (int)roundf((float)i * desc[k].r) : (int)(0x80000000u + 4u * (unsigned)steps);
-}
+// pixel (x_i, c + round(i r)) belongs to chain c and each chain is one sequential float32 sum, added in the
+// reference's order.  Input and output are interleaved volumes (ivol_index: 16 bytes = 4 neighbouring columns of
+// one row), the kernel reads one and writes the other, and every memory operation moves whole 16-byte units:
+// a unit is stored by exactly one wave (shallow) or block (steep), which computes the up to three chains of a
+// neighbour that cross its units itself (3 of 61 / 64 chains are such a halo) instead of sharing units.
 
-// Shallow slices (mode 1: the sweep runs along x, the 64 chains of a wave are 64 consecutive y).
-// At step i the wave's elements are one contiguous 256-byte run whose start is wave-uniform, so the
-// common case is: scalar address arithmetic, one buffer load, one add, one buffer store per step.
-// A batch of 8 steps is classified (uniformly) as outside the image, fully inside, or on the border
-// (per-lane clamping); 48 loads are kept in flight per lane.
-// Padding of the offset table per slice: the shallow kernel prefetches kShAhead steps ahead.
-static constexpr int kShU = 8, kShNB = 6, kShAhead = kShU * kShNB;
-__host__ __device__ inline int sh_off_stride(int steps) { return ((steps + kShU - 1) / kShU) * kShU + 2 * kShAhead; }
-
-// One batch of kShU consecutive steps for the 64 chains c0 + lane of a wave.  Step i touches row
-// y = c0 + lane + off[i] of column start + i*s.  Every step gets its own buffer descriptor: base =
-// the column, size = one column, so the buffer unit's range check clips the chains to the image
-// (a lane outside the column, or a step past the end, loads 0 / drops its store) and the only
-// per-lane arithmetic is one add.  No branch: every batch issues exactly kShU memory operations,
-// so the compiler can count them and never waits for more than it needs.
-struct ShAddr {
-    __amdgpu_buffer_rsrc_t rs[kShU];
-    unsigned voff[kShU];
-};
-// col: running pointer to the column of step i0 (advanced by step_elems per step, also past the
-// last step: those descriptors are never dereferenced because their lane offsets are out of range).
-__device__ __forceinline__ void sh_addr(ShAddr& A, float*& col, long step_elems, const int* __restrict__ off, int i0,
-                                        int H, int c04, int lane4) {
-    // 8 dwords with scalar vector loads: the table is padded and its rows are 32-byte aligned
-    const int4* op = reinterpret_cast<const int4*>(off + i0);
-    const int4 oa = op[0], ob = op[1];
-    const int o[kShU] = {oa.x, oa.y, oa.z, oa.w, ob.x, ob.y, ob.z, ob.w};
-#pragma unroll
-    for (int j = 0; j < kShU; ++j) {
-        A.voff[j] = (unsigned)lane4 + (unsigned)(c04 + o[j]);  // negative rows wrap to >= 2^31: out of range
-        A.rs[j] = __builtin_amdgcn_make_buffer_rsrc(col, 0, (unsigned)H * 4u, 0x00020000);
-        col += step_elems;
+// ---- shallow slices (mode 1: the sweep runs along x, a wave's chains are neighbouring rows)
+// Per group of 4 columns (4 sweep steps) a wave issues one 16-byte load and one 16-byte store per lane: lane rho is
+// the row where its chain sits at the group's first step.  During the group a chain moves on by 0 or 1 row per
+// step (|r| <= 1), always in the direction of sign(r), so the running sums are kept in row coordinates: after a
+// step that moves the chains the accumulator is shifted by one lane (DPP wave_shr), inputs and outputs need no
+// shuffling, and at the end of the group the accumulator is shifted back by the group's total.
+// Lane rho <-> chain a + sg*(rho - 3), sg = sign(r): lanes 0..2 are the halo (the chains that reach the wave's
+// first rows during a group), lanes 3..60 the 58 chains whose rows the wave stores, lanes 61..63 would fall off
+// the 64-row window after 3 moves and are not used.
+static constexpr int kShP = 12;                 // groups (loads of 1 KB) in flight per wave
+static constexpr int kShOwn = 58, kShHalo = 3;
+// Table per slice, one word per group in sweep order: 16 * (chain offset round(i r) at the group's first step) |
+// bit j: the chains move between the group's steps j and j+1.  Steps outside the image (the padding columns of
+// the last group) repeat the nearest offset.  Past the last group: 2^30, an out-of-range row for every lane.
+__host__ __device__ inline int sh_tab_stride(int W) { return (((W + 3) / 4 + 2 * kShP) + 3) & ~3; }
+__global__ void k_groups(const IntegralDesc* __restrict__ desc, int* __restrict__ tab, int W, int stride) {
+    const int G = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
+    if (G >= stride) return;
+    const IntegralDesc d = desc[k];
+    const int W4 = (W + 3) / 4;
+    int word = 0x40000000;
+    if (d.mode == 1 && G < W4) {
+        int o[4];
+        for (int j = 0; j < 4; ++j) {
+            const int x = d.s > 0 ? 4 * G + j : 4 * (W4 - 1 - G) + 3 - j;
+            const int i = min(max(d.s > 0 ? x : W - 1 - x, 0), W - 1);      // sweep step of column x (imgproc.h:54-55)
+            o[j] = (int)roundf((float)i * d.r);
+        }
+        word = o[0] * 16 | (o[1] != o[0] ? 1 : 0) | (o[2] != o[1] ? 2 : 0) | (o[3] != o[2] ? 4 : 0);
     }
+    tab[(size_t)k * stride + G] = word;
 }
 
-__device__ __forceinline__ void integral_shallow(float* __restrict__ vol, int W, int H, const IntegralDesc& d, int k,
-                                                 const int* __restrict__ offtab) {
-    constexpr int NB = kShNB, U = kShU;
-    const int lane4 = (threadIdx.x & 63) * 4;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float lane_shr1(float v) {  // lane i <- lane i-1 (lane 0 <- 0)
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float lane_shl1(float v) {  // lane i <- lane i+1 (lane 63 <- 0)
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, true));
+}
+
+__device__ __forceinline__ void integral_shallow(const float* __restrict__ src, float* __restrict__ dst, int W, int H,
+                                                 const IntegralDesc& d, int k, const int* __restrict__ tab) {
+    constexpr int P = kShP;
+    static_assert(P % 4 == 0, "the table is read four groups at a time");
+    const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int steps = W, span = H;
-    const int* off = offtab + (size_t)k * sh_off_stride(steps);
-    const int last_off = off[steps - 1] / 4;  // the table holds byte offsets
-    const int cmin = -max(0, last_off), cmax = span - 1 - min(0, last_off);
-    const int c0 = cmin + ((int)blockIdx.x * 4 + wave) * 64;
-    if (c0 > cmax) return;
-    const int start = d.s < 0 ? steps - 1 : 0;
-    const long step_elems = (long)d.s * H;
-    float* col_f = vol + (size_t)k * W * H + (size_t)start * H;  // column of the next step to fetch
-    float* col_c = col_f;                                         // column of the next step to consume
-    float acc = 0.f;
-    float v[NB][U];
+    const int W4 = (W + 3) >> 2;
+    const int last_off = (int)roundf((float)(W - 1) * d.r);
+    const int cmin = -max(0, last_off), cmax = H - 1 - min(0, last_off);
+    const int lo = cmin + ((int)blockIdx.x * 4 + wave) * kShOwn;  // the wave stores the rows of chains lo .. lo + 57
+    if (lo > cmax) return;
+    const int sg = d.r < 0.f ? -1 : 1;
+    const int a = sg > 0 ? lo : lo + kShOwn - 1;
+    const int lanebase = (a + sg * (lane - kShHalo)) * 16;  // byte offset of the lane's row inside a group at chain offset 0
+    const bool own = lane >= kShHalo && lane < kShHalo + kShOwn;
+    const int* tb = tab + (size_t)k * sh_tab_stride(W);
+    const size_t sl = ivol_slice_floats(W, H);
+    const long gstride = (long)d.s * H * 4;  // floats from a group to the next one of the sweep
+    const size_t g0 = d.s > 0 ? 0 : (size_t)(W4 - 1) * H * 4;
+    const float* gf = src + (size_t)k * sl + g0;  // group of the next fetch
+    float* gc = dst + (size_t)k * sl + g0;        // group of the next store
+    const bool up = d.s > 0;                      // columns of a group in sweep order: x y z w, or w z y x
+    constexpr unsigned OOB = 0x80000000u;
+    u32x4 v[P];
+    auto fetch = [&](int word, u32x4& r) {
+        // one descriptor per group: base = the group, size = one group, so rows outside the image (and every row of
+        // the groups past the end) read as 0 and their stores are dropped
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gf), 0, (unsigned)H * 16u, 0x00020000);
+        r = __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)(lanebase + (word & ~15)), 0, 0);
+        gf += gstride;
+    };
 #pragma unroll
-    for (int b = 0; b < NB; ++b) {
-        ShAddr A;
-        sh_addr(A, col_f, step_elems, off, b * U, H, c0 * 4, lane4);
-#pragma unroll
-        for (int j = 0; j < U; ++j) v[b][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(A.rs[j], A.voff[j], 0, 0));
+    for (int p = 0; p < P; p += 4) {
+        const int4 w4 = *reinterpret_cast<const int4*>(tb + p);
+        fetch(w4.x, v[p]); fetch(w4.y, v[p + 1]); fetch(w4.z, v[p + 2]); fetch(w4.w, v[p + 3]);
     }
-    // Loads of a chain never alias its earlier stores (each pixel belongs to one chain and is visited
-    // once), so values are fetched kShAhead steps ahead of the running sum.
-    for (int i0 = 0; i0 < steps; i0 += NB * U) {
+    // The first fetches are waited for here, once: the compiler orders them freely, and its wait at the loop header has
+    // to cover the entry as well as the back edge -- with anything pending on entry it waits for (nearly) all memory
+    // operations in every iteration.
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            ShAddr A;
-            sh_addr(A, col_c, step_elems, off, i0 + b * U, H, c0 * 4, lane4);
+    for (int p = 0; p < P; ++p) asm volatile("" : "+v"(v[p]));
+    float acc = 0.f;
+    for (int G0 = 0; G0 < W4; G0 += P) {
 #pragma unroll
-            for (int j = 0; j < U; ++j) {
-                acc = v[b][j] + acc;  // out-of-image loads are +0: 0 + acc == acc exactly (acc >= +0)
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc), A.rs[j], A.voff[j], 0, 0);
+        for (int p = 0; p < P; p += 4) {
+            const int4 wc = *reinterpret_cast<const int4*>(tb + G0 + p);
+            const int4 wn = *reinterpret_cast<const int4*>(tb + G0 + p + P);
+            const int wcur[4] = {wc.x, wc.y, wc.z, wc.w}, wnext[4] = {wn.x, wn.y, wn.z, wn.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int word = wcur[q];
+                const u32x4 in = v[p + q];
+                const float i0 = __uint_as_float(up ? in.x : in.w), i1 = __uint_as_float(up ? in.y : in.z),
+                            i2 = __uint_as_float(up ? in.z : in.y), i3 = __uint_as_float(up ? in.w : in.x);
+                // out-of-image elements are +0: 0 + acc == acc exactly (acc >= +0)
+                acc = i0 + acc; const float o0 = acc; if (word & 1) acc = lane_shr1(acc);
+                acc = i1 + acc; const float o1 = acc; if (word & 2) acc = lane_shr1(acc);
+                acc = i2 + acc; const float o2 = acc; if (word & 4) acc = lane_shr1(acc);
+                acc = i3 + acc; const float o3 = acc;
+                const int moved = __builtin_popcount(word & 7);
+                if (moved > 0) acc = lane_shl1(acc);
+                if (moved > 1) acc = lane_shl1(acc);
+                if (moved > 2) acc = lane_shl1(acc);
+                u32x4 out;
+                out.x = __float_as_uint(up ? o0 : o3); out.y = __float_as_uint(up ? o1 : o2);
+                out.z = __float_as_uint(up ? o2 : o1); out.w = __float_as_uint(up ? o3 : o0);
+                const auto rs = __builtin_amdgcn_make_buffer_rsrc(gc, 0, (unsigned)H * 16u, 0x00020000);
+                __builtin_amdgcn_raw_buffer_store_b128(out, rs, own ? (unsigned)(lanebase + (word & ~15)) : OOB, 0, 0);
+                gc += gstride;
+                fetch(wnext[q], v[p + q]);
             }
-            sh_addr(A, col_f, step_elems, off, i0 + (NB + b) * U, H, c0 * 4, lane4);
-#pragma unroll
-            for (int j = 0; j < U; ++j) v[b][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(A.rs[j], A.voff[j], 0, 0));
         }
     }
 }
 
-// Steep slices (mode 2: the sweep runs along y, chains run across x) would read and write one
-// 4-byte element per 4 KiB-strided lane in the y-fastest layout.  They go through LDS tiles
-// instead: a block owns XC neighbouring chains, loads [XC + 32 columns] x [32 sweep steps] with
-// 128-byte segments along y, wave 0 runs the 64 sequential sums on the tile, and the tile is
-// stored back the same way.  The next tile's loads are in flight while the current one is
-// summed and stored.  Only elements that belong to the block's own chains are written.
+// ---- steep slices (mode 2: the sweep runs along y, chains run across x)
+// They go through LDS tiles: a block computes 64 neighbouring chains, loads [64 + 32 (+4 to start on a group)
+// columns] x [32 sweep steps] as 16-byte units (4 columns of one row), wave 0 runs the 64 sequential sums on the
+// tile, and the units whose first column belongs to one of the block's first 60 chains are stored (their other
+// three columns belong to the next three chains at most: the halo).  The next tile's loads are in flight while
+// the current one is summed and stored.
+static constexpr int kStOwn = 60;
 template <int XC>
-__device__ __forceinline__ void integral_steep(float* __restrict__ vol, int W, int H, const IntegralDesc& d, int k) {
-    constexpr int TS = 32, TW = XC + TS, PASSES = TW / 8;
+__device__ __forceinline__ void integral_steep(const float* __restrict__ src, float* __restrict__ dst, int W, int H,
+                                               const IntegralDesc& d, int k) {
+    constexpr int TS = 32, TW = XC + TS + 4, NG = TW / 4, PASSES = (NG + 7) / 8;
     __shared__ float tile[2][TW][TS + 1];
-    const int steps = H, span = W;
+    const int steps = H, span = W, W4 = (W + 3) >> 2;
     const int last_off = (int)roundf((float)(steps - 1) * d.r);
     const int cmin = -max(0, last_off), cmax = span - 1 - min(0, last_off);
-    const int c0 = cmin + (int)blockIdx.x * XC;
+    const int c0 = cmin + (int)blockIdx.x * kStOwn;
     if (c0 > cmax) return;
-    const int c_hi = min(c0 + XC - 1, cmax);
     const int start = d.s < 0 ? steps - 1 : 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int prow = tid & 31, pcol = tid >> 5;  // load/store mapping: 8 columns x 32 rows per pass
+    const int prow = tid & 31, pgrp = tid >> 5;  // load/store mapping: 8 groups x 32 rows per pass
     const int ntiles = (steps + TS - 1) / TS;
-    // The slice through a buffer descriptor: a column left or right of the image gives a byte offset
-    // that is negative (wraps above 2^31) or >= W*H*4, both out of range, so only the sweep
-    // direction needs an explicit test.  Out-of-range loads return 0, stores are dropped, and no
-    // memory operation sits behind a branch: the compiler counts them exactly, which lets the
-    // loads of two tiles stay in flight behind the stores of the previous ones.
-    const auto rs = __builtin_amdgcn_make_buffer_rsrc(vol + (size_t)k * W * H, 0, (unsigned)((size_t)W * H * 4), 0x00020000);
+    // Units outside the image get an out-of-range offset: loads return 0, stores are dropped, and no memory
+    // operation sits behind a branch, so the compiler counts them exactly and the loads of two tiles stay in
+    // flight behind the stores of the previous ones.
+    const size_t sl = ivol_slice_floats(W, H);
+    const auto rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src) + (size_t)k * sl, 0, (unsigned)(sl * 4), 0x00020000);
+    const auto rs_out = __builtin_amdgcn_make_buffer_rsrc(dst + (size_t)k * sl, 0, (unsigned)(sl * 4), 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
-    const int colB = H * 4;
     auto off_at = [&](int i) { return (int)roundf((float)i * d.r); };  // chain offset at step i (imgproc.h:70-71)
-    auto xbase = [&](int t) { return c0 + min(off_at(t * TS), off_at(min(t * TS + TS - 1, steps - 1))); };
-    auto load_tile = [&](int t, float (&regs)[PASSES]) {
-        const int i = t * TS + prow, xb = xbase(t);
-        const unsigned yb = i < steps ? (unsigned)((start + i * d.s) * 4) : OOB;
-        const unsigned cb = (unsigned)((xb + pcol) * colB) + yb;
+    // first column of tile t: the leftmost column of the block's chains over the tile's steps, rounded down to a group
+    auto xbase = [&](int t) { return (c0 + min(off_at(t * TS), off_at(min(t * TS + TS - 1, steps - 1)))) & ~3; };
+    auto unit_off = [&](int xg, int i) {  // byte offset of the unit of group xg at sweep step i
+        return (xg >= 0 && xg < W4 && i < steps) ? (unsigned)((xg * H + start + i * d.s) << 4) : OOB;
+    };
+    auto load_tile = [&](int t, u32x4 (&regs)[PASSES]) {
+        const int i = t * TS + prow, xg0 = xbase(t) >> 2;
 #pragma unroll
-        for (int p = 0; p < PASSES; ++p)
-            regs[p] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, cb + (unsigned)(p * 8 * colB), 0, 0));
+        for (int p = 0; p < PASSES; ++p) {
+            const int g = p * 8 + pgrp;
+            regs[p] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, g < NG ? unit_off(xg0 + g, i) : OOB, 0, 0);
+        }
     };
     float acc = 0.f;
-    auto process = [&](int t, float (&regs)[PASSES]) {  // regs hold tile t on entry, tile t + 2 on exit
+    auto process = [&](int t, u32x4 (&regs)[PASSES]) {  // regs hold tile t on entry, tile t + 2 on exit
         const int buf = t & 1, i0 = t * TS, xb = xbase(t);
 #pragma unroll
-        for (int p = 0; p < PASSES; ++p) tile[buf][p * 8 + pcol][prow] = regs[p];
+        for (int p = 0; p < PASSES; ++p) {
+            const int g = p * 8 + pgrp;
+            if (g < NG) {
+                tile[buf][4 * g + 0][prow] = __uint_as_float(regs[p].x);
+                tile[buf][4 * g + 1][prow] = __uint_as_float(regs[p].y);
+                tile[buf][4 * g + 2][prow] = __uint_as_float(regs[p].z);
+                tile[buf][4 * g + 3][prow] = __uint_as_float(regs[p].w);
+            }
+        }
         __syncthreads();
         load_tile(t + 2, regs);  // past the last tile every load is out of range
         if (wave == 0) {
-            // Lane = chain c0 + lane.  At step ii the chain sits in tile column lane + (off_ii - min off): always
+            // Lane = chain c0 + lane.  At step ii the chain sits in tile column lane + off_ii - (xb - c0): always
             // inside the tile.  No validity test is needed here: elements outside the image or past the last
-            // step were loaded as +0 (acc + 0 == acc exactly), every tile element belongs to exactly one chain,
-            // and the write-back below only stores elements of the block's own chains inside the image.
+            // step were loaded as +0 (acc + 0 == acc exactly) and every tile element belongs to exactly one chain.
             const int my_d = off_at(min(i0 + (lane & 31), steps - 1)) - (xb - c0);  // lane j < 32: step i0 + j
             // all 32 reads are issued before the dependent chain of adds (they never alias: one element per
             // step), so the chain costs 32 adds, not 32 LDS round trips
@@ -1286,19 +1346,23 @@ __device__ __forceinline__ void integral_steep(float* __restrict__ vol, int W, i
             }
         }
         __syncthreads();
-        {  // only elements of the block's own chains are written back
+        {  // a unit is stored by the block that owns the chain of its first column
             const int i = i0 + prow;
-            const int o = off_at(i);
-            const unsigned yb = i < steps ? (unsigned)((start + i * d.s) * 4) : OOB;
+            const int o = off_at(min(i, steps - 1));
 #pragma unroll
             for (int p = 0; p < PASSES; ++p) {
-                const int x = xb + p * 8 + pcol, c = x - o;
-                const unsigned voff = (c >= c0 && c <= c_hi) ? (unsigned)(x * colB) + yb : OOB;
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(tile[buf][p * 8 + pcol][prow]), rs, voff, 0, 0);
+                const int g = p * 8 + pgrp;
+                const int fc = xb + 4 * g - o;  // chain of the unit's first column
+                u32x4 out;
+                const int gg = g < NG ? g : 0;
+                out.x = __float_as_uint(tile[buf][4 * gg + 0][prow]); out.y = __float_as_uint(tile[buf][4 * gg + 1][prow]);
+                out.z = __float_as_uint(tile[buf][4 * gg + 2][prow]); out.w = __float_as_uint(tile[buf][4 * gg + 3][prow]);
+                const bool mine = g < NG && fc >= c0 && fc < c0 + kStOwn;
+                __builtin_amdgcn_raw_buffer_store_b128(out, rs_out, mine ? unit_off((xb >> 2) + g, i) : OOB, 0, 0);
             }
         }
     };
-    float ra[PASSES], rb[PASSES];
+    u32x4 ra[PASSES], rb[PASSES];
     load_tile(0, ra);
     load_tile(1, rb);
     for (int t = 0; t < ntiles; t += 2) {
@@ -1309,16 +1373,21 @@ __device__ __forceinline__ void integral_steep(float* __restrict__ vol, int W, i
 
 // One launch for all slices: blockIdx.y = slice, and the slice's mode picks the sweep.  Shallow and
 // steep slices are independent, so their (latency-bound) blocks overlap instead of running as two
-// kernels back to back.  Grid x covers the steep case (64 chains per block); a shallow block takes
-// 256 chains and the surplus blocks of a shallow slice exit at once.
-__global__ void __launch_bounds__(256) k_integral(float* __restrict__ vol, int W, int H,
+// kernels back to back.  Grid x covers the steep case (60 chains per block); a shallow block takes
+// 232 chains and the surplus blocks of a shallow slice exit at once.
+__global__ void __launch_bounds__(256) k_integral(const float* __restrict__ src, float* __restrict__ dst, int W, int H,
                                                   const IntegralDesc* __restrict__ desc,
-                                                  const int* __restrict__ offtab, int only_mode) {
+                                                  const int* __restrict__ tab, int only_mode) {
     const int k = blockIdx.y;
     const IntegralDesc d = desc[k];
     if (only_mode && d.mode != only_mode) return;  // timing experiment (FDCM_INT_ONLY): one kind of slice only
-    if (d.mode == 1) integral_shallow(vol, W, H, d, k, offtab);
-    else if (d.mode == 2) integral_steep<64>(vol, W, H, d, k);
+    if (d.mode == 1) integral_shallow(src, dst, W, H, d, k, tab);
+    else if (d.mode == 2) integral_steep<64>(src, dst, W, H, d, k);
+    else {  // nothing to integrate (imgproc.h:43): the slice moves as it is
+        const size_t sl = ivol_slice_floats(W, H);
+        for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < sl; q += (size_t)gridDim.x * 256)
+            dst[(size_t)k * sl + q] = src[(size_t)k * sl + q];
+    }
 }
 
 // ------------------------------------------------------------------------------------------ driver
@@ -1344,7 +1413,7 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after) {
     const int HW64 = (H + 63) / 64;
     const size_t npix = (size_t)W * H, nvox = npix * m;
     const long nrows = (long)m * H, ncols = (long)m * W;
-    fm->vol.reserve(nvox * sizeof(float));
+    fm->vol.reserve(std::max(nvox, (size_t)m * ivol_slice_floats(W, H)) * sizeof(float));  // the integrated volume comes back here, interleaved
     fm->bitmap.reserve((size_t)ncols * HW64 * 8);
     const long nchunks = (long)m * HW64;  // (slice, 64-row chunk) pairs
     // Tuning overrides, read once (measurements and tests only).
@@ -1537,21 +1606,24 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after) {
     FDCM_HIP(hipEventRecord(ev[3], st));
     const bool want_sqrt = fm->distance == FDCM_L2;
     if (stop_after >= 2) {
-        const unsigned pblocks = (unsigned)((npix + 255) / 256);
+        const size_t nq = ivol_slice_floats(W, H);
+        fm->ivol.reserve((size_t)m * nq * sizeof(float));
+        float* ivol = fm->ivol.as<float>();
+        const unsigned pblocks = (unsigned)((nq + 255) / 256);
         const int sq = want_sqrt ? 1 : 0;
-        if (m == 30) hipLaunchKernelGGL(k_propagate_reg<30>, dim3(pblocks), dim3(256), 0, st, vol, npix, d_prop, sq);
-        else if (m == 60) hipLaunchKernelGGL(k_propagate_reg<60>, dim3(pblocks), dim3(256), 0, st, vol, npix, d_prop, sq);
-        else if (m == 90) hipLaunchKernelGGL(k_propagate_reg<90>, dim3(pblocks), dim3(256), 0, st, vol, npix, d_prop, sq);
-        else if (m == 120) hipLaunchKernelGGL(k_propagate_reg<120>, dim3(pblocks), dim3(256), 0, st, vol, npix, d_prop, sq);
-        else if (m == 180) hipLaunchKernelGGL(k_propagate_reg<180>, dim3(pblocks), dim3(256), 0, st, vol, npix, d_prop, sq);
+        if (m == 30) hipLaunchKernelGGL(k_propagate_reg<30>, dim3(pblocks), dim3(256), 0, st, (const float*)vol, ivol, W, H, d_prop, sq);
+        else if (m == 60) hipLaunchKernelGGL(k_propagate_reg<60>, dim3(pblocks), dim3(256), 0, st, (const float*)vol, ivol, W, H, d_prop, sq);
+        else if (m == 90) hipLaunchKernelGGL(k_propagate_reg<90>, dim3(pblocks), dim3(256), 0, st, (const float*)vol, ivol, W, H, d_prop, sq);
+        else if (m == 120) hipLaunchKernelGGL(k_propagate_reg<120>, dim3(pblocks), dim3(256), 0, st, (const float*)vol, ivol, W, H, d_prop, sq);
+        else if (m == 180) hipLaunchKernelGGL(k_propagate_reg<180>, dim3(pblocks), dim3(256), 0, st, (const float*)vol, ivol, W, H, d_prop, sq);
         else {
             int bd = 256;
             while (bd > 64 && (size_t)m * bd * sizeof(float) > 64 * 1024) bd >>= 1;
             const size_t lds = (size_t)m * bd * sizeof(float);
             if (lds > 64 * 1024)
                 FDCM_HIP(hipFuncSetAttribute((const void*)k_propagate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(k_propagate, dim3((unsigned)((npix + bd - 1) / bd)), dim3(bd), lds, st, vol, npix, m, d_prop,
-                               (int)fm->n_prop, sq);
+            hipLaunchKernelGGL(k_propagate, dim3((unsigned)((nq + bd - 1) / bd)), dim3(bd), lds, st, (const float*)vol, ivol, W, H, m,
+                               d_prop, (int)fm->n_prop, sq);
         }
     } else if (want_sqrt) {
         hipLaunchKernelGGL(k_sqrt, dim3((unsigned)((nvox + 255) / 256)), dim3(256), 0, st, vol, nvox);
@@ -1559,17 +1631,18 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after) {
     FDCM_HIP(hipEventRecord(ev[4], st));
     if (stop_after >= 3) {
         const int chains = 2 * (W > H ? W : H);
-        const int steps = W > H ? W : H;
-        const int off_stride = sh_off_stride((int)steps);
-        fm->offtab.reserve((size_t)m * off_stride * sizeof(int));
-        int* d_off = fm->offtab.as<int>();
-        if (!(fm->off_m == m && fm->off_steps == steps)) {  // the offsets only depend on the keys (fixed per handle) and the sweep length
-            hipLaunchKernelGGL(k_offsets, dim3((unsigned)((off_stride + 255) / 256), (unsigned)m), dim3(256), 0, st, d_int, d_off, (int)steps, off_stride);
-            fm->off_m = m; fm->off_steps = steps;
+        const int tab_stride = sh_tab_stride(W);
+        fm->offtab.reserve((size_t)m * tab_stride * sizeof(int));
+        int* d_tab = fm->offtab.as<int>();
+        if (!(fm->off_m == m && fm->off_steps == W)) {  // the table only depends on the keys (fixed per handle) and the size
+            hipLaunchKernelGGL(k_groups, dim3((unsigned)((tab_stride + 255) / 256), (unsigned)m), dim3(256), 0, st, d_int, d_tab, W, tab_stride);
+            fm->off_m = m; fm->off_steps = W;
         }
         static const int env_int_only = getenv("FDCM_INT_ONLY") ? atoi(getenv("FDCM_INT_ONLY")) : 0;  // timing experiment
-        hipLaunchKernelGGL(k_integral, dim3((unsigned)((chains + 63) / 64), (unsigned)m), dim3(256), 0, st, vol, W, H, d_int, d_off, env_int_only);
+        hipLaunchKernelGGL(k_integral, dim3((unsigned)((chains + kStOwn - 1) / kStOwn), (unsigned)m), dim3(256), 0, st,
+                           (const float*)fm->ivol.as<float>(), vol, W, H, d_int, d_tab, env_int_only);
     }
+    fm->vol_stage = stop_after >= 3 ? 3 : (stop_after == 2 ? 2 : 1);
     FDCM_HIP(hipEventRecord(ev[5], st));
     FDCM_HIP(hipGetLastError());
     fm->build_pending = true;  // not waited for here: see finish_build

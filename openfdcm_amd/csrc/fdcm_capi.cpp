@@ -50,7 +50,7 @@ static void destroy(fdcm_featuremap* fm) {
     if (!fm) return;
     (void)hipSetDevice(fm->device);
     if (fm->stream) (void)hipStreamSynchronize(fm->stream);
-    fm->vol.release(); fm->bitmap.release(); fm->coldesc.release(); fm->offtab.release(); fm->stack.release(); fm->plan.release(); fm->stage.release();
+    fm->vol.release(); fm->ivol.release(); fm->bitmap.release(); fm->coldesc.release(); fm->offtab.release(); fm->stack.release(); fm->plan.release(); fm->stage.release();
     fm->s_scene.release(); fm->s_pairs.release(); fm->s_records.release(); fm->s_flags.release(); fm->s_out.release(); fm->s_work.release(); fm->s_tail.release(); fm->s_tail_out.release();
     fm->s_counter.release(); fm->s_stage.release();
     if (fm->timing.created)
@@ -145,7 +145,15 @@ int fdcm_featuremap_slice(const fdcm_featuremap* fm, int64_t k, float* out_host)
         finish_build(const_cast<fdcm_featuremap*>(fm));
         FDCM_HIP(hipSetDevice(fm->device));
         const size_t npix = (size_t)fm->W * fm->H;
-        FDCM_HIP(hipMemcpy(out_host, fm->vol.as<float>() + (size_t)k * npix, npix * sizeof(float), hipMemcpyDeviceToHost));
+        if (!fm->current_interleaved()) {  // a partial build (tests of the stages) that stopped before the propagation
+            FDCM_HIP(hipMemcpy(out_host, fm->vol.as<float>() + (size_t)k * npix, npix * sizeof(float), hipMemcpyDeviceToHost));
+            return;
+        }
+        const size_t sl = ivol_slice_floats(fm->W, fm->H);
+        std::vector<float> tmp(sl);
+        FDCM_HIP(hipMemcpy(tmp.data(), fm->current() + (size_t)k * sl, sl * sizeof(float), hipMemcpyDeviceToHost));
+        for (int64_t x = 0; x < fm->W; ++x)
+            for (int64_t y = 0; y < fm->H; ++y) out_host[(size_t)x * fm->H + y] = tmp[ivol_index((int)x, (int)y, fm->H)];
     });
 }
 
@@ -153,7 +161,7 @@ int fdcm_featuremap_device_volume(const fdcm_featuremap* fm, const float** devic
     return guarded([&] {
         require(fm && device_ptr, "null argument");
         finish_build(const_cast<fdcm_featuremap*>(fm));  // the caller may read it from any stream
-        *device_ptr = fm->vol.as<float>();
+        *device_ptr = fm->current();
     });
 }
 
@@ -179,11 +187,19 @@ int fdcm_featuremap_from_slices(const float* keys, int64_t depth, const float* v
         fm->depth_param = depth; fm->m = depth; fm->W = width; fm->H = height;
         fm->tx = scene_translation[0]; fm->ty = scene_translation[1];
         fm->keys.assign(keys, keys + depth);
-        const size_t bytes = (size_t)depth * width * height * sizeof(float);
-        if (bytes) {
-            fm->vol.reserve(bytes);
-            FDCM_HIP(hipMemcpy(fm->vol.p, volume_host, bytes, hipMemcpyHostToDevice));
+        require(width <= 16384 && height <= 16384, "feature size above 16384 is not supported");
+        const size_t sl = ivol_slice_floats(width, height);
+        if (depth && sl) {  // into the interleaved layout the search reads, one slice at a time
+            fm->vol.reserve((size_t)depth * sl * sizeof(float));
+            std::vector<float> tmp(sl, 0.f);
+            for (int64_t k = 0; k < depth; ++k) {
+                const float* src = volume_host + (size_t)k * width * height;
+                for (int64_t x = 0; x < width; ++x)
+                    for (int64_t y = 0; y < height; ++y) tmp[ivol_index((int)x, (int)y, height)] = src[(size_t)x * height + y];
+                FDCM_HIP(hipMemcpy(fm->vol.as<float>() + (size_t)k * sl, tmp.data(), sl * sizeof(float), hipMemcpyHostToDevice));
+            }
         }
+        fm->vol_stage = 3;
         upload_keys_only(fm);
         *out = fm;
     });

@@ -79,6 +79,13 @@ FDCM_HD float lin_spaced_value(int mode, float low, float high, float step, int 
     return (i == size1) ? high : (low + (float)i * step);
 }
 
+// ---------------------------------------------------------------- the integrated volume
+// From the propagation on the volume lives in a layout whose 64-byte sectors hold 4 x by 4 y pixels:
+// [k][x/4][y][x%4] (columns of the last group past W are padding).  The search gathers single floats at positions that step by about one pixel per
+// translation, in any direction; in the y-fastest layout of the build 16 steps along x touch 16 sectors, here 4 to 8.
+FDCM_HD size_t ivol_slice_floats(int64_t W, int64_t H) { return (size_t)((W + 3) / 4) * (size_t)H * 4; }
+FDCM_HD size_t ivol_index(int x, int y, int64_t H) { return ((size_t)(x >> 2) * (size_t)H + (size_t)y) * 4 + (size_t)(x & 3); }
+
 // ---------------------------------------------------------------- handles
 struct Timing {
     hipEvent_t ev[9] = {};  // 0-5 build stages, 6-7 search kernels, 8 search download
@@ -105,7 +112,15 @@ struct fdcm_featuremap {
     float tx = 0, ty = 0;
     std::vector<float> keys;
     // device state
-    fdcm::DevBuf vol;      // m*W*H float, [k][x][y]
+    // The volume moves between two buffers: the sweeps write the distance transforms into `vol`, y-fastest [k][x][y];
+    // the propagation reads them and writes `ivol` in the interleaved layout (ivol_index); the line integral reads
+    // `ivol` and writes its sums back into `vol`, interleaved -- which is what the search gathers from.
+    fdcm::DevBuf vol;      // max(m*W*H, m*ivol_slice_floats) floats
+    fdcm::DevBuf ivol;     // m*ivol_slice_floats floats
+    int vol_stage = 0;     // what the handle holds: 1 = transforms (vol, y-fastest; staged test builds), 2 = propagated
+                           // (ivol, interleaved; staged test builds), 3 = integrated (vol, interleaved): complete
+    const float* current() const { return vol_stage == 2 ? ivol.as<float>() : vol.as<float>(); }
+    bool current_interleaved() const { return vol_stage >= 2; }
     fdcm::DevBuf bitmap;   // m*W*ceil(H/64) uint64 seed bits along y
     fdcm::DevBuf coldesc;  // m*ceil(H/64)*W column-chunk descriptors (16 B)
     fdcm::DevBuf offtab;   // m * max(W,H) chain offsets of the line integral
