@@ -103,7 +103,7 @@ struct fdcm_featuremap {
     int distance = 0;
     bool bitmap_clean = false;   // k_coldesc left the seed bitmap zeroed (it clears what it reads)
     long bitmap_words = 0;       // size the bitmap had then
-    int off_m = 0, off_steps = 0;  // the chain-offset table in `offtab` is valid for this depth and sweep length
+    int off_m = 0, off_steps = 0;  // the group table in `offtab` is valid for this depth and feature width
     bool build_pending = false;  // the last build is queued on `stream` but has not been waited for
     bool throughput_mode = false; // a frame-pipeline slot: other frames share the GPU, launch shapes favour throughput
     float build_host_ms = 0.f;   // host time of that call up to its first kernel launch
@@ -123,7 +123,7 @@ struct fdcm_featuremap {
     bool current_interleaved() const { return vol_stage >= 2; }
     fdcm::DevBuf bitmap;   // m*W*ceil(H/64) uint64 seed bits along y
     fdcm::DevBuf coldesc;  // m*ceil(H/64)*W column-chunk descriptors (16 B)
-    fdcm::DevBuf offtab;   // m * max(W,H) chain offsets of the line integral
+    fdcm::DevBuf offtab;   // per slice: one word per group of 4 columns for the shallow sweeps of the line integral (k_groups)
     fdcm::DevBuf stack;    // K2 scratch: per row a (v, f, z) stack of W entries
     fdcm::DevBuf plan;     // RasterLine[] | PropStep[] | IntegralDesc[] | keys[]
     fdcm::PinnedBuf stage; // host staging for the plan
