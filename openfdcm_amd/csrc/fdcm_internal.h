@@ -83,7 +83,14 @@ FDCM_HD float lin_spaced_value(int mode, float low, float high, float step, int 
 // From the propagation on the volume lives in a layout whose 64-byte sectors hold 4 x by 4 y pixels:
 // [k][x/4][y][x%4] (columns of the last group past W are padding).  The search gathers single floats at positions that step by about one pixel per
 // translation, in any direction; in the y-fastest layout of the build 16 steps along x touch 16 sectors, here 4 to 8.
-FDCM_HD size_t ivol_slice_floats(int64_t W, int64_t H) { return (size_t)((W + 3) / 4) * (size_t)H * 4; }
+// Slices are 4352 bytes longer than their pixels: feature sizes are powers of two in practice, and a candidate's
+// gathers read the same place of up to `depth` slices -- with slices a power of two apart they all fall on the same
+// memory channels (config 2': the search kernels took 0.24 - 0.36 ms depending on where the allocation landed,
+// 0.21 - 0.22 ms with the padding; 256 bytes of padding were not enough, 2 to 20 KB all the same).
+#ifndef FDCM_SLICE_PAD
+#define FDCM_SLICE_PAD 1088
+#endif
+FDCM_HD size_t ivol_slice_floats(int64_t W, int64_t H) { return (size_t)((W + 3) / 4) * (size_t)H * 4 + FDCM_SLICE_PAD; }
 FDCM_HD size_t ivol_index(int x, int y, int64_t H) { return ((size_t)(x >> 2) * (size_t)H + (size_t)y) * 4 + (size_t)(x & 3); }
 
 // ---------------------------------------------------------------- handles

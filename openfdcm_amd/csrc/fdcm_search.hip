@@ -82,14 +82,14 @@ __device__ __forceinline__ float wave_max_f(float v) {
 // evaluate<Dt3Cpu> for one line and one translation, dt3cpu.cpp:153-173.  L = per-wave LDS lines
 // (x1,y1,x2,y2,bin), off = sceneTranslation + translation.
 __device__ __forceinline__ float line_value(const float* __restrict__ vol, const float* L, int i, float offx,
-                                            float offy, size_t W4, size_t H) {
+                                            float offy, size_t SL, size_t H) {
     const float* l = L + 5 * i;
     const int x1 = (int)(l[0] + offx), y1 = (int)(l[1] + offy);  // translate then cast<int>()
     const int x2 = (int)(l[2] + offx), y2 = (int)(l[3] + offy);
     const size_t bin = (size_t)__float_as_int(l[4]);
-    // the integrated volume is interleaved (ivol_index): W4 = x groups per slice
-    const float a = vol[((bin * W4 + (size_t)(x1 >> 2)) * H + (size_t)y1) * 4 + (size_t)(x1 & 3)];
-    const float b = vol[((bin * W4 + (size_t)(x2 >> 2)) * H + (size_t)y2) * 4 + (size_t)(x2 & 3)];
+    // the integrated volume is interleaved (ivol_index): SL = floats per slice
+    const float a = vol[bin * SL + ((size_t)(x1 >> 2) * H + (size_t)y1) * 4 + (size_t)(x1 & 3)];
+    const float b = vol[bin * SL + ((size_t)(x2 >> 2) * H + (size_t)y2) * 4 + (size_t)(x2 & 3)];
     return f_abs(a - b);
 }
 
@@ -145,7 +145,7 @@ struct OptState {
     int n_t, lane, B, WIN;
     bool batch_rule;
     bool reset_back;  // IndulgentOptimize: the negative direction compares against the initial score again
-    size_t W, H;  // W: x groups of the interleaved volume (ceil(width / 4))
+    size_t W, H;  // W: floats per slice of the interleaved volume (ivol_slice_floats)
     float tx, ty, savx, savy;
     long long lim_p, lim_n;
 };
@@ -389,7 +389,10 @@ __global__ void __launch_bounds__(1024) k_wl_scatter(const SearchParams P, long 
     }
 }
 
-__global__ void __launch_bounds__(256) k_search(const SearchParams P) {
+#ifndef FDCM_SEARCH_WPE
+#define FDCM_SEARCH_WPE 4
+#endif
+__global__ void __launch_bounds__(256, FDCM_SEARCH_WPE) k_search(const SearchParams P) {
     extern __shared__ float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int t, local;
@@ -466,7 +469,7 @@ __global__ void __launch_bounds__(256) k_search(const SearchParams P) {
     unsigned long long n_eval = 0;
     if (valid) {
         OptState o;
-        o.L = L; o.sc = sc; o.n_t = n_t; o.W = (size_t)((P.W + 3) / 4); o.H = (size_t)P.H; o.tx = P.tx; o.ty = P.ty;
+        o.L = L; o.sc = sc; o.n_t = n_t; o.W = ivol_slice_floats(P.W, P.H); o.H = (size_t)P.H; o.tx = P.tx; o.ty = P.ty;
         o.savx = savx; o.savy = savy; o.lane = lane;
         o.B = P.optimizer == FDCM_BATCH_OPTIMIZE ? P.batch : 1; o.WIN = P.win; o.batch_rule = P.optimizer == FDCM_BATCH_OPTIMIZE;
         o.reset_back = P.optimizer == FDCM_INDULGENT_OPTIMIZE;
