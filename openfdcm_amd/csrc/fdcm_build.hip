@@ -1424,8 +1424,7 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after) {
     static const int env_segments = getenv("FDCM_K2_SEGMENTS") ? atoi(getenv("FDCM_K2_SEGMENTS")) : 0;
     static const int env_force_redo = getenv("FDCM_K2_FORCE_REDO") ? atoi(getenv("FDCM_K2_FORCE_REDO")) : 0;
     static const bool env_debug = getenv("FDCM_K2_DEBUG") != nullptr;  // per-wave clock stamps, printed after the sweep
-    static const bool env_unfused = getenv("FDCM_K2_UNFUSED") != nullptr;  // blocking builds: three launches instead of one
-    static const bool env_fused = getenv("FDCM_K2_FUSED") != nullptr;      // pipeline slots: one launch instead of three
+    static const bool env_unfused = getenv("FDCM_K2_UNFUSED") != nullptr;  // three launches (k_env, k_addend, k_fill) instead of one
     static const int env_experiment = getenv("FDCM_K2_EXPERIMENT") ? atoi(getenv("FDCM_K2_EXPERIMENT")) : 0;  // debug kernels only
     // The segmented sweep (k_sweep) is the default: config 2 (480 chunks) 0.47 ms against 0.65 ms for the
     // one-wave-per-chunk kernel, config 3 (1920 chunks) 1.75 against 1.79 ms.  Its scratch is 20 B per pixel against
@@ -1518,10 +1517,9 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after) {
 #define FDCM_K2(RR, CC, SS, PP) hipLaunchKernelGGL((k_pass2_l2<RR, CC, SS, PP>), dim3(wblocks), dim3(256), 0, st, d_desc, vol, W, H, HW64, nwaves, sv, sf, sz, gate)
             if (segmented) {
                 // up to 4 segments: 256-thread blocks with a 16-entry ring; up to 8: 512-thread blocks with an 8-entry ring
-                // (both 64 KB of ring + 3 KB: two blocks per CU).  One launch for a blocking build (the phases' tails
-                // overlap between chunks), three for the slots of a frame pipeline (no wave idles at a barrier while the
-                // GPU has other frames' work).
-                const bool three = fm->throughput_mode ? !env_fused : env_unfused;
+                // (both 64 KB of ring + 3 KB: two blocks per CU).  One launch: the phases' tails overlap between chunks
+                // (the three-launch form is kept for measurements: FDCM_K2_UNFUSED).
+                const bool three = env_unfused;
 #define FDCM_SWEEP(CC, NN, DD) hipLaunchKernelGGL((k_sweep<CC, NN, DD>), dim3((unsigned)nchunks), dim3(64 * S), 0, st, d_desc, vol, W, H, HW64, S, part_w, kb, env_force_redo, env_experiment)
 #define FDCM_ENV(CC, NN, DD) hipLaunchKernelGGL((k_env<CC, NN, DD>), dim3((unsigned)nchunks), dim3(64 * S), 0, st, d_desc, W, H, HW64, S, kb, env_experiment)
                 if (!three) {

@@ -112,7 +112,6 @@ struct fdcm_featuremap {
     long bitmap_words = 0;       // size the bitmap had then
     int off_m = 0, off_steps = 0;  // the group table in `offtab` is valid for this depth and feature width
     bool build_pending = false;  // the last build is queued on `stream` but has not been waited for
-    bool throughput_mode = false; // a frame-pipeline slot: other frames share the GPU, launch shapes favour throughput
     float build_host_ms = 0.f;   // host time of that call up to its first kernel launch
     // geometry
     int64_t W = 0, H = 0, m = 0;
