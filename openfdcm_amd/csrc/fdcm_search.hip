@@ -80,17 +80,27 @@ __device__ __forceinline__ float wave_max_f(float v) {
 }
 
 // evaluate<Dt3Cpu> for one line and one translation, dt3cpu.cpp:153-173.  L = per-wave LDS lines
-// (x1,y1,x2,y2,bin), off = sceneTranslation + translation.
-__device__ __forceinline__ float line_value(const float* __restrict__ vol, const float* L, int i, float offx,
-                                            float offy, size_t SL, size_t H) {
+// (x1,y1,x2,y2,bin), off = sceneTranslation + translation.  The two reads are split from the subtraction so that a
+// caller can have the reads of many lines in flight (SL = floats per slice, ivol_slice_floats).
+struct LineReads {
+    float a, b;
+};
+__device__ __forceinline__ LineReads line_reads(const float* __restrict__ vol, const float* L, int i, float offx,
+                                                float offy, size_t SL, unsigned H) {
     const float* l = L + 5 * i;
     const int x1 = (int)(l[0] + offx), y1 = (int)(l[1] + offy);  // translate then cast<int>()
     const int x2 = (int)(l[2] + offx), y2 = (int)(l[3] + offy);
-    const size_t bin = (size_t)__float_as_int(l[4]);
-    // the integrated volume is interleaved (ivol_index): SL = floats per slice
-    const float a = vol[bin * SL + ((size_t)(x1 >> 2) * H + (size_t)y1) * 4 + (size_t)(x1 & 3)];
-    const float b = vol[bin * SL + ((size_t)(x2 >> 2) * H + (size_t)y2) * 4 + (size_t)(x2 & 3)];
-    return f_abs(a - b);
+    const float* slice = vol + (size_t)__float_as_int(l[4]) * SL;  // the two halves of a wave work on different lines
+    // the integrated volume is interleaved (ivol_index)
+    LineReads r;
+    r.a = slice[((unsigned)(x1 >> 2) * H + (unsigned)y1) * 4u + (unsigned)(x1 & 3)];
+    r.b = slice[((unsigned)(x2 >> 2) * H + (unsigned)y2) * 4u + (unsigned)(x2 & 3)];
+    return r;
+}
+__device__ __forceinline__ float line_value(const float* __restrict__ vol, const float* L, int i, float offx,
+                                            float offy, size_t SL, size_t H) {
+    const LineReads r = line_reads(vol, L, i, offx, offy, SL, (unsigned)H);
+    return f_abs(r.a - r.b);
 }
 
 // score_per_line.sum() (dt3cpu.cpp:175): Eigen 3.4.0 redux (Redux.h, LinearVectorizedTraversal,
@@ -103,15 +113,24 @@ __device__ __forceinline__ float pair_score(const float* __restrict__ vol, const
     float acc[4] = {0.f, 0.f, 0.f, 0.f};  // 0 + v == v exactly (v >= +0)
     if (active) {
         if (aligned >= 8) {
+            // Four blocks (16 lines per lane, 32 reads) are fetched before the first of them is added: one memory
+            // round trip where a block at a time made four.  A short last group repeats its last block's reads and
+            // adds 0 for them (acc + 0 == acc exactly).
             const int nblk = aligned2 / 8;
-#pragma unroll 4
-            for (int i = 0; i < nblk; ++i) {
-                const int b = 8 * i + 4 * h;
-                float v[4];
+            for (int i0 = 0; i0 < nblk; i0 += 4) {
+                LineReads r[4][4];
 #pragma unroll
-                for (int l = 0; l < 4; ++l) v[l] = line_value(vol, L, b + l, offx, offy, W, H);
+                for (int ii = 0; ii < 4; ++ii) {
+                    const int b = 8 * min(i0 + ii, nblk - 1) + 4 * h;
 #pragma unroll
-                for (int l = 0; l < 4; ++l) acc[l] = acc[l] + v[l];
+                    for (int l = 0; l < 4; ++l) r[ii][l] = line_reads(vol, L, b + l, offx, offy, W, (unsigned)H);
+                }
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii) {
+                    const bool real = i0 + ii < nblk;
+#pragma unroll
+                    for (int l = 0; l < 4; ++l) acc[l] = acc[l] + (real ? f_abs(r[ii][l].a - r[ii][l].b) : 0.f);
+                }
             }
         } else if (aligned == 4 && h == 0) {
 #pragma unroll
