@@ -99,8 +99,11 @@ int fdcm_featuremap_keys(const fdcm_featuremap* fm, float* keys /* depth floats,
 int fdcm_featuremap_slice(const fdcm_featuremap* fm, int64_t k, float* out_host);
 /* Whole volume on the device (read-only view, valid until free/rebuild).  Layout: 4 neighbouring x are
  * interleaved so that a 64-byte sector holds 4 x by 4 y pixels (the search's gathers step about one pixel per
- * translation in any direction): pixel (k, x, y) is element ((k * ceil(W/4) + x/4) * H + y) * 4 + x%4. */
+ * translation in any direction), and slices are a little longer than their pixels (power-of-two slice
+ * strides would put one pixel of every slice on the same memory channel): pixel (k, x, y) is element
+ * k * floats_per_slice + ((x/4) * H + y) * 4 + x%4, floats_per_slice from fdcm_featuremap_device_volume_stride. */
 int fdcm_featuremap_device_volume(const fdcm_featuremap* fm, const float** device_ptr);
+int fdcm_featuremap_device_volume_stride(const fdcm_featuremap* fm, int64_t* floats_per_slice);
 int fdcm_featuremap_last_timing(const fdcm_featuremap* fm, fdcm_build_timing* t);
 /* Dt3Cpu(dt3map, sceneTranslation, featureSize) constructor (dt3cpu.h:55-58): adopt caller slices. */
 int fdcm_featuremap_from_slices(const float* keys, int64_t depth, const float* volume_host /* [k][x][y] */,

@@ -165,6 +165,13 @@ int fdcm_featuremap_device_volume(const fdcm_featuremap* fm, const float** devic
     });
 }
 
+int fdcm_featuremap_device_volume_stride(const fdcm_featuremap* fm, int64_t* floats_per_slice) {
+    return guarded([&] {
+        require(fm && floats_per_slice, "null argument");
+        *floats_per_slice = fm->current_interleaved() ? (int64_t)ivol_slice_floats(fm->W, fm->H) : fm->W * fm->H;
+    });
+}
+
 int fdcm_featuremap_last_timing(const fdcm_featuremap* fm, fdcm_build_timing* t) {
     return guarded([&] {
         require(fm && t, "null argument");

@@ -84,9 +84,15 @@ class DeviceFeatureMap:
         return out
 
     def device_pointer(self):
+        """Address of the volume in HBM; layout: element k * device_slice_stride() + ((x // 4) * H + y) * 4 + x % 4."""
         p = C.c_void_p()
         capi.check(capi.lib().fdcm_featuremap_device_volume(self._h, C.byref(p)))
         return p.value
+
+    def device_slice_stride(self):
+        n = C.c_int64()
+        capi.check(capi.lib().fdcm_featuremap_device_volume_stride(self._h, C.byref(n)))
+        return n.value
 
     def build_timing(self):
         t = capi.BuildTiming()

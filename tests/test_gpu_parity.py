@@ -235,6 +235,25 @@ def test_adopted_volume_and_dt3_map_roundtrip(amd):
     assert len(a) == len(b) and all(x.score == y.score and x.tmpl_idx == y.tmpl_idx for x, y in zip(a, b))
 
 
+def test_device_volume_layout_is_the_documented_one():
+    """fdcm_featuremap_device_volume + _stride (include/fdcm.h): pixel (k, x, y) at k * stride + ((x/4) * H + y) * 4 + x%4,
+    for a width that is not a multiple of 4 and for an adopted volume."""
+    import ctypes
+    from openfdcm_amd.engine import DeviceFeatureMap
+    hip = ctypes.CDLL("libamdhip64.so")
+    scene = small_scene(150, 24, 5)
+    dev = DeviceFeatureMap.build(scene, depth=6, coeff=5.0, padding=1.3, distance=0)
+    for fm in (dev, DeviceFeatureMap.from_volume(dev.keys, dev.volume(), dev.scene_translation)):
+        W, H, m, stride = fm.width, fm.height, fm.depth, fm.device_slice_stride()
+        assert stride >= ((W + 3) // 4) * H * 4
+        raw = np.zeros(m * stride, dtype=np.float32)
+        assert hip.hipMemcpy(ctypes.c_void_p(raw.ctypes.data), ctypes.c_void_p(fm.device_pointer()), ctypes.c_size_t(raw.nbytes), 2) == 0
+        vol = fm.volume()  # [k][x][y] through fdcm_featuremap_slice
+        x, y = np.meshgrid(np.arange(W), np.arange(H), indexing="ij")
+        for k in range(m):
+            assert np.array_equal(raw[k * stride + ((x // 4) * H + y) * 4 + x % 4], vol[k])
+
+
 def test_concentric_range_strategy(amd):
     """ConcentricRangeStrategy through the mirrored API vs the oracle's restatement (concentricrange.cpp:29-60)."""
     openfdcm = amd
