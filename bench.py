@@ -46,7 +46,7 @@ HBM_PEAK_GBS = 8000.0
 # V/16 of column descriptors and never materialises it); propagation reads V and writes V; line integral likewise.
 STAGE_BYTES_V = {"pass2_ms": 3.0, "propagate_ms": 2.0, "integral_ms": 2.0}
 STAGE_KERNELS = {"seeds_ms": "k_seeds", "pass1_ms": "k_coldesc",
-                 "pass2_ms": "L2 sweep: k_sweep (blocking) / k_env + k_addend + k_fill (pipeline slots); L1: k_l1_forward + k_l1_backward",
+                 "pass2_ms": "L2 / L2^2: k_sweep (+ the gated k_pass2_l2 redo); L1: k_l1_forward + k_l1_backward",
                  "propagate_ms": "k_propagate_reg", "integral_ms": "k_integral"}
 DIST_NAMES = {0: "L2", 1: "L2_SQUARED", 2: "L1"}
 # templates per GPU of the BASELINE configs (4 and 5 are sharded over 8 GPUs)

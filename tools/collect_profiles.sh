@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collect the round's judged measurements on the GPU box into gpurun_out/<tag>/ (copy into profiles/ afterwards).
-# usage (inside gpurun): bash tools/collect_profiles.sh r02
+# usage (inside gpurun): bash tools/collect_profiles.sh <out dir under gpurun_out> [profiles/ prefix, default r02]
 # The program goes directly after `--` (no env / bash -c hop under rocprofv3); the queue count bench.py asks for is
 # exported here because under rocprofv3 the GPU is initialised before python starts.
 R=$(cd "$(dirname "$0")/.." && pwd)
@@ -9,8 +9,6 @@ mkdir -p $OUT
 export GPU_MAX_HW_QUEUES=8
 export TMPDIR=/tmp
 cd /tmp
-python3 $R/bench.py > $OUT/bench.json 2> $OUT/bench.err
-python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_cmd.json 2>> $OUT/bench.err
 stats() {  # stats <name> <program args...>: rocprofv3 --kernel-trace --stats summary of a command
   local name=$1; shift
   rm -rf /tmp/ks_$name
@@ -27,6 +25,11 @@ pmc() {  # pmc <name> <program args...>: HBM bytes per kernel launch (two passes
 stats bench_config2p python3 $R/bench.py --cpu-sample 0
 stats bench_config2p_frames1 python3 $R/bench.py --cpu-sample 0 --frames 1 --single-frames 0
 pmc config2p python3 $R/bench.py --frames 1 --steps 5 --warmup 2 --cpu-sample 0 --single-frames 0
+# bench.py reports `roofline.traffic` from profiles/*pmc_traffic*config2p*.json when that file was measured on the running
+# library: put the fresh one there (this copy of the repository is scratch) before the judged bench lines are taken
+cp $OUT/pmc_traffic_config2p.json $R/profiles/${2:-r02}_pmc_traffic_config2p.json
+python3 $R/bench.py > $OUT/bench.json 2> $OUT/bench.err
+python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_cmd.json 2>> $OUT/bench.err
 for cfg in 3 5; do
   python3 $R/tools/run_config.py --config $cfg --check none --reps 7 --search --templates 200 > $OUT/run_config$cfg.json 2>> $OUT/bench.err
   stats config$cfg python3 $R/tools/run_config.py --config $cfg --check none --reps 7 --search --templates 200
