@@ -1202,7 +1202,8 @@ __device__ __forceinline__ void integral_shallow(const float* __restrict__ src, 
     const int W4 = (W + 3) >> 2;
     const int last_off = (int)roundf((float)(W - 1) * d.r);
     const int cmin = -max(0, last_off), cmax = H - 1 - min(0, last_off);
-    const int lo = cmin + ((int)blockIdx.x * 4 + wave) * kShOwn;  // the wave stores the rows of chains lo .. lo + 57
+    if (wave != 0) return;  // one working wave per workgroup: see k_integral
+    const int lo = cmin + (int)blockIdx.x * kShOwn;  // the wave stores the rows of chains lo .. lo + 57
     if (lo > cmax) return;
     const int sg = d.r < 0.f ? -1 : 1;
     const int a = sg > 0 ? lo : lo + kShOwn - 1;
@@ -1373,8 +1374,9 @@ __device__ __forceinline__ void integral_steep(const float* __restrict__ src, fl
 
 // One launch for all slices: blockIdx.y = slice, and the slice's mode picks the sweep.  Shallow and
 // steep slices are independent, so their (latency-bound) blocks overlap instead of running as two
-// kernels back to back.  Grid x covers the steep case (60 chains per block); a shallow block takes
-// 232 chains and the surplus blocks of a shallow slice exit at once.
+// kernels back to back.  A workgroup takes 58 chains of a shallow slice -- on one wave, the other three exit at once:
+// a CU can only have so many cache misses outstanding, and four such waves on one CU (105 of 256 CUs busy at
+// config 2) ran at 0.061 ms where one per workgroup, spread over all CUs, runs at 0.051 -- or 60 chains of a steep one.
 __global__ void __launch_bounds__(256) k_integral(const float* __restrict__ src, float* __restrict__ dst, int W, int H,
                                                   const IntegralDesc* __restrict__ desc,
                                                   const int* __restrict__ tab, int only_mode) {
@@ -1637,7 +1639,7 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after) {
             fm->off_m = m; fm->off_steps = W;
         }
         static const int env_int_only = getenv("FDCM_INT_ONLY") ? atoi(getenv("FDCM_INT_ONLY")) : 0;  // timing experiment
-        hipLaunchKernelGGL(k_integral, dim3((unsigned)((chains + kStOwn - 1) / kStOwn), (unsigned)m), dim3(256), 0, st,
+        hipLaunchKernelGGL(k_integral, dim3((unsigned)((chains + kShOwn - 1) / kShOwn), (unsigned)m), dim3(256), 0, st,
                            (const float*)fm->ivol.as<float>(), vol, W, H, d_int, d_tab, env_int_only);
     }
     fm->vol_stage = stop_after >= 3 ? 3 : (stop_after == 2 ? 2 : 1);
