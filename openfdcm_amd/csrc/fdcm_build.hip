@@ -728,9 +728,10 @@ __device__ __forceinline__ void env_phase(const ColDesc* __restrict__ desc, int 
 // that one compact loop body serves every entry; the owner entries collect in an LDS ring and go to HBM in
 // bursts, so that the loads of the walk do not queue behind stores.
 template <int KL, int NB, bool DBG>
-__device__ __forceinline__ void addend_phase(int W, int S, int part_w, const K2Buf& B, int force_mod, unsigned (*l_pk)[64],
+__device__ __forceinline__ void addend_phase(int W, int S, int part_w, const K2Buf& B, int force_mod_x, unsigned (*l_pk)[64],
                                              float (*l_b)[64], int (*e_v)[64], float (*e_f)[64], float (*e_z)[64]) {
     // l_pk / l_b: the last KL owner entries of each row; e_*: the batch (NB entries) being walked
+    const int force_mod = force_mod_x & 0xffff, xp = DBG ? force_mod_x >> 16 : 0;  // xp: timing experiments of the debug build
     const int lane = threadIdx.x & 63;
     const long chunk = blockIdx.x;
     const size_t NR = (size_t)B.NR;
@@ -739,6 +740,7 @@ __device__ __forceinline__ void addend_phase(int W, int S, int part_w, const K2B
     const EnvEntry* ent = B.ent + r * (size_t)B.eslots;
     long long* dbg = DBG ? B.dbg + ((size_t)chunk * kSegMax) * 16 : nullptr;
     long long n_batches = 0;
+    int n_quirk = 0, n_hbm = 0, n_probe = 0, n_far = 0;
     if (DBG && lane == 0) dbg[11] = wall_clock64();
     // Segment table of the row: stream index i lies in segment w for i in [o_w, o_{w+1}), at slot i + K_w.  The
     // junction checks: every test against a segment's bottom column must also push on the real stack, where that
@@ -767,11 +769,14 @@ __device__ __forceinline__ void addend_phase(int W, int S, int part_w, const K2B
         for (int w = 1; w < kSegMax; ++w) k = i >= o[w] ? K[w] : k;
         return i + k;
     };
-    int pend_v = 0, pend_st = -1, last_st = -1, lc = 0, flushed = 0, pi1 = 0, pi2 = 0, pi3 = 0;
+    int pend_v = 0, pend_st = -1, last_st = -1, lc = 0, flushed = 0;
+    int pi[3] = {0, 0, 0}, part = 0, bnd = part_w;  // pi[j]: the last list entry whose first pixel is <= (j + 1) * part_w
     int optr = 0;  // owner list index whose first pixel is <= the column looked up last (columns only grow)
     float pend_f = 0.f;
     auto list_pk = [&](int i) -> unsigned {
+        if (DBG) ++n_probe;
         if (i >= lc - KL) return l_pk[i & (KL - 1)][lane];
+        if (DBG) ++n_hbm;
         const unsigned a0 = own[i].pk;  // older than the LDS window (rare): from the list in HBM, consumed in place
         unsigned v;
         asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "v"(a0));
@@ -789,11 +794,12 @@ __device__ __forceinline__ void addend_phase(int W, int S, int part_w, const K2B
     // value the reference reads back at v: g[v] = addend_o + (v - v_o)^2 with o the owner of pixel v.  The
     // columns of successive entries grow, so o is found with a pointer that only moves forward.
     auto finalize = [&](int st_next) {
-        const bool owns = pend_st >= 0 && pend_st < st_next && pend_st > last_st;
+        const bool owns = pend_st < st_next && pend_st > last_st;  // (last_st >= -1, so a pending entry exists)
         const bool quirk = owns && pend_st > pend_v;
         float b = pend_f;
-        if (__builtin_amdgcn_ballot_w64(quirk) != 0ull) {
+        if (__builtin_amdgcn_ballot_w64(quirk && !(xp & 8)) != 0ull) {
             if (quirk) {
+                if (DBG) ++n_quirk;
                 // last list entry whose first pixel is <= pend_v, at or after optr: two steps forward (rows along a scene
                 // line need one per entry), else gallop back from the tail (the owner is a few entries back) and bisect
                 if (optr + 1 < lc && (int)(list_pk(optr + 1) >> 16) <= pend_v) {
@@ -811,6 +817,7 @@ __device__ __forceinline__ void addend_phase(int W, int S, int part_w, const K2B
                         }
                     }
                 }
+                if (DBG && lc - optr > KL) ++n_far;
                 const unsigned pk = list_pk(optr);
                 const float dv = (float)(pend_v - (int)(pk & 0xffffu));  // dv * dv rounds like float(long(dv * dv))
                 b = list_b(optr) + dv * dv;
@@ -819,9 +826,10 @@ __device__ __forceinline__ void addend_phase(int W, int S, int part_w, const K2B
         if (owns) {
             l_pk[lc & (KL - 1)][lane] = ((unsigned)pend_st << 16) | (unsigned)pend_v;
             l_b[lc & (KL - 1)][lane] = b;
-            pi1 = pend_st <= part_w ? lc : pi1;
-            pi2 = pend_st <= 2 * part_w ? lc : pi2;
-            pi3 = pend_st <= 3 * part_w ? lc : pi3;
+            if (__builtin_expect(pend_st > bnd, 0)) {  // first pixels grow: a part boundary is crossed three times per row
+                while (part < 3 && pend_st > bnd) { pi[part++] = max(lc - 1, 0); bnd += part_w; }
+                if (part == 3) bnd = 0x7fffffff;
+            }
             last_st = pend_st;
             ++lc;
         }
@@ -830,11 +838,12 @@ __device__ __forceinline__ void addend_phase(int W, int S, int part_w, const K2B
         const int fmax = __builtin_amdgcn_readfirstlane(wave_max(lc - flushed));
         for (int e = 0; e < fmax; ++e) {
             const int i = flushed + e;
-            if (i < lc) own[i] = OwnEntry{l_pk[i & (KL - 1)][lane], l_b[i & (KL - 1)][lane]};
+            if (i < lc && !(xp & 1)) own[i] = OwnEntry{l_pk[i & (KL - 1)][lane], l_b[i & (KL - 1)][lane]};
         }
         flushed = lc;
     };
     const int tmax = __builtin_amdgcn_readfirstlane(wave_max(total));
+    const float Wf = (float)W;
     EnvEntry nxt[NB];
 #pragma unroll
     for (int u = 0; u < NB; ++u) nxt[u] = ent[slot_of(min(u, total - 1))];
@@ -842,27 +851,49 @@ __device__ __forceinline__ void addend_phase(int W, int S, int part_w, const K2B
         if (DBG) ++n_batches;
 #pragma unroll
         for (int u = 0; u < NB; ++u) { e_v[u][lane] = nxt[u].v; e_f[u][lane] = nxt[u].f; e_z[u][lane] = nxt[u].z; }
+        if (!(xp & 4))
 #pragma unroll
         for (int u = 0; u < NB; ++u) nxt[u] = ent[slot_of(min(i0 + NB + u, total - 1))];  // in flight during this batch
         const int un = min(NB, tmax - i0);
+        // four entries at a time: their LDS reads and first pixels do not depend on one another, only the list does
 #pragma unroll 1
-        for (int u = 0; u < un; ++u) {
-            const bool valid = i0 + u < total;
-            const float z = e_z[u][lane];
-            // first pixel above z: the entry takes over there (while (z[k+1] < q) ++k)
-            const int st = z < 0.f ? 0 : (!(z < (float)W) ? W : (int)floorf(z) + 1);
-            finalize(valid ? st : -1);  // -1: nothing is finalised (pend_st >= 0 > -1)
-            if (valid) { pend_v = e_v[u][lane]; pend_f = e_f[u][lane]; pend_st = st; }
+        for (int u0 = 0; u0 < un; u0 += 4) {
+            int v4[4], st4[4];
+            float f4[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float z = e_z[u0 + j][lane];
+                v4[j] = e_v[u0 + j][lane]; f4[j] = e_f[u0 + j][lane];
+                // first pixel above z: the entry takes over there (while (z[k+1] < q) ++k); -1 past the row's last entry
+                // (and past the batch: un need not be a multiple of 4, NB is): nothing is finalised (pend_st >= 0 > -1)
+                // (0 below 0, W from W on; the clamps keep it to four instructions: max(z, -1) floors to -1 for every z
+                // below 0, min(z, W - 1/2) to W - 1 for every z from W - 1 on)
+                const int st = (int)floorf(__builtin_fminf(__builtin_fmaxf(z, -1.f), Wf - 0.5f)) + 1;
+                st4[j] = (i0 + u0 + j < total && u0 + j < un) ? st : -1;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (!(xp & 2)) finalize(st4[j]);
+                if (st4[j] >= 0) { pend_v = v4[j]; pend_f = f4[j]; pend_st = st4[j]; }
+            }
         }
         if (__builtin_amdgcn_ballot_w64(lc - flushed >= KL / 2) != 0ull) flush();  // a batch adds at most NB < KL / 2
     }
     finalize(W);
     flush();
     B.lcount[r] = lc;
-    B.partidx[r] = pi1; B.partidx[NR + r] = pi2; B.partidx[2 * NR + r] = pi3;
+    for (; part < 3; ++part) pi[part] = max(lc - 1, 0);
+    B.partidx[r] = pi[0]; B.partidx[NR + r] = pi[1]; B.partidx[2 * NR + r] = pi[2];
     const bool forced = force_mod > 0 && chunk % force_mod == 0;  // test hook: exercise the redo path
     if ((__builtin_amdgcn_ballot_w64(!ok) != 0ull || forced) && lane == 0) B.flags[chunk] = 1;
-    if (DBG && lane == 0) { dbg[12] = wall_clock64(); dbg[13] = n_batches; dbg[14] = __builtin_amdgcn_readfirstlane(wave_max(lc)); }
+    if (DBG) {
+        const int q = wave_max(n_quirk), hb = wave_max(n_hbm), pr = wave_max(n_probe), fr = wave_max(n_far), tt = wave_max(total);
+        if (lane == 0) {
+            dbg[12] = wall_clock64(); dbg[13] = n_batches; dbg[14] = __builtin_amdgcn_readfirstlane(wave_max(lc));
+            long long* dx = B.dbg + ((size_t)chunk * kSegMax + (kSegMax - 1)) * 16;  // slots of a wave that does not exist (S <= 4 here)
+            dx[0] = q; dx[1] = hb; dx[2] = pr; dx[3] = fr; dx[4] = tt;
+        }
+    }
 }
 
 // Pure fill (imgproc.h:122-128) from the owner list; wave p of a block fills the pixels
@@ -1522,7 +1553,7 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after) {
                 // (both 64 KB of ring + 3 KB: two blocks per CU).  One launch: the phases' tails overlap between chunks
                 // (the three-launch form is kept for measurements: FDCM_K2_UNFUSED).
                 const bool three = env_unfused;
-#define FDCM_SWEEP(CC, NN, DD) hipLaunchKernelGGL((k_sweep<CC, NN, DD>), dim3((unsigned)nchunks), dim3(64 * S), 0, st, d_desc, vol, W, H, HW64, S, part_w, kb, env_force_redo, env_experiment)
+#define FDCM_SWEEP(CC, NN, DD) hipLaunchKernelGGL((k_sweep<CC, NN, DD>), dim3((unsigned)nchunks), dim3(64 * S), 0, st, d_desc, vol, W, H, HW64, S, part_w, kb, (env_force_redo & 0xffff) | (DD ? (env_experiment >> 8) << 16 : 0), env_experiment & 0xff)
 #define FDCM_ENV(CC, NN, DD) hipLaunchKernelGGL((k_env<CC, NN, DD>), dim3((unsigned)nchunks), dim3(64 * S), 0, st, d_desc, W, H, HW64, S, kb, env_experiment)
                 if (!three) {
                     if (S <= 4) { if (env_debug) FDCM_SWEEP(16, 256, true); else FDCM_SWEEP(16, 256, false); }
@@ -1571,6 +1602,28 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after) {
                             S, nw, flagged, sum[0] / nw, mx[0], sum[1] / nw, mx[1], sum[2] / nw, mx[2], sum[3] / nw, mx[3], sum[4] / nw, mx[4],
                             sum[5] / nw, mx[5], cnt[0] / nw, cmx[0], cnt[1] / nw, cmx[1], cnt[2] / nw, cmx[2], cnt[3] / nw, cmx[3],
                             cnt[4] / nw, cmx[4], ad_sum / nchunks, ad_max, ab_sum / nchunks, ab_max, lc_max);
+                    {  // the blocks that finish their addend pass last: where their time went
+                        long long t0 = 0x7fffffffffffffffll;
+                        for (long ch = 0; ch < nchunks; ++ch) for (int w = 0; w < S; ++w) t0 = std::min(t0, d[((size_t)ch * kSegMax + w) * 16]);
+                        std::vector<std::pair<double, long>> ends;
+                        for (long ch = 0; ch < nchunks; ++ch) ends.push_back({(d[(size_t)ch * kSegMax * 16 + 12] - t0) / 100.0, ch});
+                        std::sort(ends.begin(), ends.end());
+                        for (size_t i = ends.size() > 6 ? ends.size() - 6 : 0; i < ends.size(); ++i) {
+                            const long ch = ends[i].second;
+                            double st = 1e30, scan = 0, loop = 0, envend = 0;
+                            for (int w = 0; w < S; ++w) {
+                                const long long* e = &d[((size_t)ch * kSegMax + w) * 16];
+                                st = std::min(st, (e[0] - t0) / 100.0); scan = std::max(scan, (e[2] - e[1]) / 100.0);
+                                loop = std::max(loop, (e[4] - e[3]) / 100.0); envend = std::max(envend, (e[5] - t0) / 100.0);
+                            }
+                            const long long* e = &d[(size_t)ch * kSegMax * 16];
+                            const long long* dx = &d[((size_t)ch * kSegMax + (kSegMax - 1)) * 16];
+                            fprintf(stderr, "[k2 debug] late block %ld: starts %.1f us, scan %.1f, loop %.1f, env ends %.1f, addend %.1f -> %.1f (%.1f us, %lld owners; "
+                                    "max per row: %lld entries, %lld lookups, %lld list reads of which %lld from HBM, %lld owners older than the window)\n",
+                                    ch, st, scan, loop, envend, (e[11] - t0) / 100.0, (e[12] - t0) / 100.0, (e[12] - e[11]) / 100.0, e[14],
+                                    S <= 4 ? dx[4] : -1, S <= 4 ? dx[0] : -1, S <= 4 ? dx[2] : -1, S <= 4 ? dx[1] : -1, S <= 4 ? dx[3] : -1);
+                        }
+                    }
                     {
                         double mhz = 0; long nm = 0;
                         if (S > 1) for (long ch = 0; ch < nchunks; ++ch) {
