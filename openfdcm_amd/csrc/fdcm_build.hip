@@ -1225,7 +1225,7 @@ __device__ __forceinline__ float lane_shl1(float v) {  // lane i <- lane i+1 (la
 }
 
 __device__ __forceinline__ void integral_shallow(const float* __restrict__ src, float* __restrict__ dst, int W, int H,
-                                                 const IntegralDesc& d, int k, const int* __restrict__ tab) {
+                                                 const IntegralDesc& d, int k, const int* __restrict__ tab, int shw) {
     constexpr int P = kShP;
     static_assert(P % 4 == 0, "the table is read four groups at a time");
     const int lane = threadIdx.x & 63;
@@ -1233,8 +1233,8 @@ __device__ __forceinline__ void integral_shallow(const float* __restrict__ src, 
     const int W4 = (W + 3) >> 2;
     const int last_off = (int)roundf((float)(W - 1) * d.r);
     const int cmin = -max(0, last_off), cmax = H - 1 - min(0, last_off);
-    if (wave != 0) return;  // one working wave per workgroup: see k_integral
-    const int lo = cmin + (int)blockIdx.x * kShOwn;  // the wave stores the rows of chains lo .. lo + 57
+    if (wave >= shw) return;  // shw = 1 (one working wave per workgroup) or 4: see k_integral
+    const int lo = cmin + ((int)blockIdx.x * shw + wave) * kShOwn;  // the wave stores the rows of chains lo .. lo + 57
     if (lo > cmax) return;
     const int sg = d.r < 0.f ? -1 : 1;
     const int a = sg > 0 ? lo : lo + kShOwn - 1;
@@ -1405,16 +1405,18 @@ __device__ __forceinline__ void integral_steep(const float* __restrict__ src, fl
 
 // One launch for all slices: blockIdx.y = slice, and the slice's mode picks the sweep.  Shallow and
 // steep slices are independent, so their (latency-bound) blocks overlap instead of running as two
-// kernels back to back.  A workgroup takes 58 chains of a shallow slice -- on one wave, the other three exit at once:
-// a CU can only have so many cache misses outstanding, and four such waves on one CU (105 of 256 CUs busy at
-// config 2) ran at 0.061 ms where one per workgroup, spread over all CUs, runs at 0.051 -- or 60 chains of a steep one.
+// kernels back to back.  A workgroup takes 60 chains of a steep slice, or 58 chains of a shallow one on one wave
+// (the other three exit at once) while the launch is small: a CU can only have so many cache misses outstanding, and
+// four such waves on one CU (105 of 256 CUs busy at config 2) ran at 0.061 ms where one per workgroup, spread over
+// all CUs, runs at 0.051.  Large launches (config 5: 25 000 workgroups) fill every CU anyway and put 4 x 58 chains on a
+// workgroup (5.9 against 6.4 ms).
 __global__ void __launch_bounds__(256) k_integral(const float* __restrict__ src, float* __restrict__ dst, int W, int H,
                                                   const IntegralDesc* __restrict__ desc,
-                                                  const int* __restrict__ tab, int only_mode) {
+                                                  const int* __restrict__ tab, int only_mode, int shw) {
     const int k = blockIdx.y;
     const IntegralDesc d = desc[k];
     if (only_mode && d.mode != only_mode) return;  // timing experiment (FDCM_INT_ONLY): one kind of slice only
-    if (d.mode == 1) integral_shallow(src, dst, W, H, d, k, tab);
+    if (d.mode == 1) integral_shallow(src, dst, W, H, d, k, tab, shw);
     else if (d.mode == 2) integral_steep<64>(src, dst, W, H, d, k);
     else {  // nothing to integrate (imgproc.h:43): the slice moves as it is
         const size_t sl = ivol_slice_floats(W, H);
@@ -1692,8 +1694,9 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after) {
             fm->off_m = m; fm->off_steps = W;
         }
         static const int env_int_only = getenv("FDCM_INT_ONLY") ? atoi(getenv("FDCM_INT_ONLY")) : 0;  // timing experiment
+        const int shw = (long)m * ((chains + kShOwn - 1) / kShOwn) > 8192 ? 4 : 1;  // working waves per workgroup of a shallow slice
         hipLaunchKernelGGL(k_integral, dim3((unsigned)((chains + kShOwn - 1) / kShOwn), (unsigned)m), dim3(256), 0, st,
-                           (const float*)fm->ivol.as<float>(), vol, W, H, d_int, d_tab, env_int_only);
+                           (const float*)fm->ivol.as<float>(), vol, W, H, d_int, d_tab, env_int_only, shw);
     }
     fm->vol_stage = stop_after >= 3 ? 3 : (stop_after == 2 ? 2 : 1);
     FDCM_HIP(hipEventRecord(ev[5], st));
