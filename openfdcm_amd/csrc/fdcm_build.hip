@@ -958,11 +958,11 @@ template <int C, int NT, bool DBG>
 __global__ void __launch_bounds__(NT) k_sweep(const ColDesc* __restrict__ desc, float* __restrict__ vol, int W, int H, int HW64,
                                               int S, int part_w, K2Buf B, int force_mod, int expm) {
     constexpr int KL = 64, NB = 16, RE = 16;
-    static_assert((size_t)C * NT * sizeof(float4) >= (size_t)(2 * KL + 3 * NB) * 64 * 4, "ring too small for the addend phase");
-    static_assert((size_t)C * NT * sizeof(float4) >= (size_t)2 * RE * 256 * 4, "ring too small for the fill phase");
+    // one LDS pool for the three phases: the construction's ring, the addend pass's lists, the fill's staging
+    constexpr size_t kPoolBytes = std::max({(size_t)C * NT * sizeof(float4), (size_t)(2 * KL + 3 * NB) * 64 * 4, (size_t)2 * RE * 256 * 4});
     __shared__ unsigned long long smask[256];
     __shared__ int cj[NT / 64 + 1][64];
-    __shared__ float4 pool[C * NT];
+    __shared__ float4 pool[kPoolBytes / sizeof(float4)];
     env_phase<C, NT, DBG>(desc, W, H, HW64, S, B, expm, smask, cj, reinterpret_cast<float4(*)[NT]>(pool));
     __syncthreads();  // every segment's stack, count and minF are in memory
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
@@ -1551,14 +1551,20 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after) {
             const int* gate = nullptr;
 #define FDCM_K2(RR, CC, SS, PP) hipLaunchKernelGGL((k_pass2_l2<RR, CC, SS, PP>), dim3(wblocks), dim3(256), 0, st, d_desc, vol, W, H, HW64, nwaves, sv, sf, sz, gate)
             if (segmented) {
-                // up to 4 segments: 256-thread blocks with a 16-entry ring; up to 8: 512-thread blocks with an 8-entry ring
-                // (both 64 KB of ring + 3 KB: two blocks per CU).  One launch: the phases' tails overlap between chunks
-                // (the three-launch form is kept for measurements: FDCM_K2_UNFUSED).
+                // One launch: the phases' tails overlap between chunks (the three-launch form is kept for measurements:
+                // FDCM_K2_UNFUSED).  More than 4 segments (FDCM_K2_SEGMENTS): 512-thread blocks with an 8-entry ring.
                 const bool three = env_unfused;
 #define FDCM_SWEEP(CC, NN, DD) hipLaunchKernelGGL((k_sweep<CC, NN, DD>), dim3((unsigned)nchunks), dim3(64 * S), 0, st, d_desc, vol, W, H, HW64, S, part_w, kb, (env_force_redo & 0xffff) | (DD ? (env_experiment >> 8) << 16 : 0), env_experiment & 0xff)
 #define FDCM_ENV(CC, NN, DD) hipLaunchKernelGGL((k_env<CC, NN, DD>), dim3((unsigned)nchunks), dim3(64 * S), 0, st, d_desc, W, H, HW64, S, kb, env_experiment)
                 if (!three) {
-                    if (S <= 4) { if (env_debug) FDCM_SWEEP(16, 256, true); else FDCM_SWEEP(16, 256, false); }
+                    // Up to 4 segments: 256-thread blocks with an 8-entry ring (the pool is then the addend pass's 45 KB: three
+                    // blocks per CU, which is also what 139 VGPRs allow).  A 16-entry ring (77 KB, two blocks per CU) is as
+                    // fast alone at config 2 and slower wherever blocks queue for a CU: config 3 1.74 -> 1.50 ms, four frames
+                    // in flight 61 -> 67 M matches/s.  (A 4-entry ring changes nothing more; capping the registers at 128
+                    // for a fourth block spills in the column loop and loses.)
+                    static const int env_ring = getenv("FDCM_K2_RING") ? atoi(getenv("FDCM_K2_RING")) : 0;  // measurement: ring entries per row in LDS
+                    if (S <= 4 && env_ring == 16) FDCM_SWEEP(16, 256, false);
+                    else if (S <= 4) { if (env_debug) FDCM_SWEEP(8, 256, true); else FDCM_SWEEP(8, 256, false); }
                     else { if (env_debug) FDCM_SWEEP(8, 512, true); else FDCM_SWEEP(8, 512, false); }
                 } else {
                     if (S <= 4) { if (env_debug) FDCM_ENV(16, 256, true); else FDCM_ENV(16, 256, false); }
