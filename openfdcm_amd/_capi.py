@@ -95,6 +95,11 @@ class FdcmError(RuntimeError):
     pass
 
 
+def loaded():
+    """True once libfdcm_hip.so (and with it /opt/rocm's HIP runtime) is in the process."""
+    return _lib is not None
+
+
 def lib():
     global _lib
     if _lib is None:

@@ -488,6 +488,8 @@ struct K2Buf {
     int* partidx;                         // [part - 1][row]: list index that owns the first pixel of fill part 1..3
     int* flags;                           // per 64-row chunk: 1 = redo with k_pass2_l2
     long long* dbg;                       // optional per-wave clock stamps and counters (FDCM_K2_DEBUG), else null
+    const int* order;                     // launch position -> chunk (longest chunks of the previous build first), or null
+    int* cost;                            // per chunk: 100 MHz ticks from the block's start to the end of its addend pass
     long NR;                              // rows of the scratch arrays (chunks * 64)
     int eslots, lslots;
 };
@@ -511,7 +513,7 @@ template <int C, int NT, bool DBG>
 __device__ __forceinline__ void env_phase(const ColDesc* __restrict__ desc, int W, int H, int HW64, int S, const K2Buf& B,
                                           int expm, unsigned long long* smask, int (*cj)[64], float4 (*ring)[NT]) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const long chunk = blockIdx.x;
+    const long chunk = B.order ? B.order[blockIdx.x] : (long)blockIdx.x;
     const long k = chunk / HW64;
     const int c = (int)(chunk - k * HW64);
     const int y = c * 64 + lane;
@@ -733,7 +735,7 @@ __device__ __forceinline__ void addend_phase(int W, int S, int part_w, const K2B
     // l_pk / l_b: the last KL owner entries of each row; e_*: the batch (NB entries) being walked
     const int force_mod = force_mod_x & 0xffff, xp = DBG ? force_mod_x >> 16 : 0;  // xp: timing experiments of the debug build
     const int lane = threadIdx.x & 63;
-    const long chunk = blockIdx.x;
+    const long chunk = B.order ? B.order[blockIdx.x] : (long)blockIdx.x;
     const size_t NR = (size_t)B.NR;
     const size_t r = (size_t)chunk * 64 + lane;
     OwnEntry* own = B.own + r * (size_t)B.lslots;
@@ -902,7 +904,7 @@ template <int RE>
 __device__ __forceinline__ void fill_phase(float* __restrict__ vol, int W, int H, int HW64, int part_w, const K2Buf& B, int p,
                                            unsigned (*f_pk)[256], float (*f_b)[256]) {
     const int tid = threadIdx.x & 255, lane = tid & 63;
-    const long chunk = blockIdx.x;
+    const long chunk = B.order ? B.order[blockIdx.x] : (long)blockIdx.x;
     const long k = chunk / HW64;
     const int c = (int)(chunk - k * HW64);
     const int y = c * 64 + lane;
@@ -963,6 +965,7 @@ __global__ void __launch_bounds__(NT) k_sweep(const ColDesc* __restrict__ desc, 
     __shared__ unsigned long long smask[256];
     __shared__ int cj[NT / 64 + 1][64];
     __shared__ float4 pool[kPoolBytes / sizeof(float4)];
+    const long long t_start = wall_clock64();
     env_phase<C, NT, DBG>(desc, W, H, HW64, S, B, expm, smask, cj, reinterpret_cast<float4(*)[NT]>(pool));
     __syncthreads();  // every segment's stack, count and minF are in memory
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
@@ -974,6 +977,7 @@ __global__ void __launch_bounds__(NT) k_sweep(const ColDesc* __restrict__ desc, 
                                   reinterpret_cast<float(*)[64]>(w32 + (2 * KL + 2 * NB) * 64));
     }
     __syncthreads();  // the chunk's owner lists are in memory
+    if (threadIdx.x == 0) B.cost[B.order ? B.order[blockIdx.x] : (long)blockIdx.x] = (int)(wall_clock64() - t_start);
     {
         unsigned* w32 = reinterpret_cast<unsigned*>(pool);
         const int nw = (int)blockDim.x >> 6;
@@ -981,6 +985,27 @@ __global__ void __launch_bounds__(NT) k_sweep(const ColDesc* __restrict__ desc, 
             fill_phase<RE>(vol, W, H, HW64, part_w, B, p, reinterpret_cast<unsigned(*)[256]>(w32),
                            reinterpret_cast<float(*)[256]>(w32 + RE * 256));
     }
+}
+
+// Launch order of the next build's chunks: by decreasing cost of this one (scenes of a stream change little from
+// frame to frame).  Blocks are dispatched in index order; when there are more blocks than the GPU holds, the
+// longest ones must not start last.  One workgroup: a counting sort over 256 cost classes.
+__global__ void __launch_bounds__(1024) k_order(const int* __restrict__ cost, int n, int* __restrict__ order) {
+    __shared__ int hist[256], cursor[256], smax;
+    const int tid = threadIdx.x;
+    if (tid < 256) hist[tid] = 0;
+    if (tid == 0) smax = 1;
+    __syncthreads();
+    int mx = 1;
+    for (int i = tid; i < n; i += 1024) mx = max(mx, cost[i]);
+    atomicMax(&smax, mx);
+    __syncthreads();
+    const float scale = 255.f / (float)smax;
+    for (int i = tid; i < n; i += 1024) atomicAdd(&hist[255 - min(255, max(0, (int)((float)cost[i] * scale)))], 1);
+    __syncthreads();
+    if (tid == 0) { int run = 0; for (int b = 0; b < 256; ++b) { cursor[b] = run; run += hist[b]; } }
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) order[atomicAdd(&cursor[255 - min(255, max(0, (int)((float)cost[i] * scale)))], 1)] = i;
 }
 
 // The same phases as three launches: no wave waits at a barrier while one wave of its block runs the addend pass, so
@@ -1488,8 +1513,22 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after) {
         const size_t o_tc = take(kSegMax * NRr * 4), o_tm = take(kSegMax * NRr * 4), o_ts = take(kSegMax * NRr * 4);
         const size_t o_lc = take(NRr * 4), o_pi = take(3 * NRr * 4), o_fl = take((size_t)nchunks * 4);
         const size_t o_dbg = take(env_debug ? (size_t)nchunks * kSegMax * 16 * 8 : 0);
+        const size_t o_ord = take((size_t)nchunks * 4), o_cost = take((size_t)nchunks * 4);
+        const void* stack_before = fm->stack.p;
         fm->stack.reserve(off);
         char* sb = (char*)fm->stack.p;
+        // Launch order: blocks are dispatched in index order, and when there are more of them than the GPU holds at once
+        // (three per CU) the long ones must not start last.  Nothing cheap predicts a chunk's time well enough (the seeded
+        // and the far columns of a chunk correlate 0.85 with it and buy 4 %), the previous build of the same shape does:
+        // scenes of a stream change little from frame to frame (config 3: 1.50 -> 1.08 ms; the first build of a handle,
+        // and every build after a change of size, runs in index order).  FDCM_K2_LPT=0 / 1 forces it off / on.
+        static const int env_lpt = getenv("FDCM_K2_LPT") ? atoi(getenv("FDCM_K2_LPT")) : -1;
+        const bool want_order = env_lpt >= 0 ? env_lpt != 0 : nchunks > 3L * device_cus(fm->device);
+        const bool have_cost = want_order && segmented && fm->k2_cost_chunks == nchunks && fm->k2_cost_w == W && stack_before == fm->stack.p;
+        if (have_cost) hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, st, (const int*)(sb + o_cost), (int)nchunks, (int*)(sb + o_ord));
+        kb.order = have_cost ? (const int*)(sb + o_ord) : nullptr;
+        kb.cost = (int*)(sb + o_cost);
+        fm->k2_cost_chunks = segmented ? nchunks : 0; fm->k2_cost_w = W;
         kb.ent = (EnvEntry*)(sb + o_ent); kb.own = (OwnEntry*)(sb + o_own);
         kb.tcnt = (int*)(sb + o_tc); kb.tminf = (float*)(sb + o_tm); kb.tslot = (int*)(sb + o_ts);
         kb.lcount = (int*)(sb + o_lc); kb.partidx = (int*)(sb + o_pi); kb.flags = (int*)(sb + o_fl);
@@ -1575,6 +1614,12 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after) {
                 }
 #undef FDCM_SWEEP
 #undef FDCM_ENV
+                if (const char* dump = getenv("FDCM_K2_DUMP_COST")) {  // measurement: the chunks' times of this build, as int32
+                    FDCM_HIP(hipStreamSynchronize(st));
+                    std::vector<int> hc((size_t)nchunks);
+                    FDCM_HIP(hipMemcpy(hc.data(), kb.cost, hc.size() * 4, hipMemcpyDeviceToHost));
+                    if (FILE* f = fopen(dump, "wb")) { fwrite(hc.data(), 4, hc.size(), f); fclose(f); }
+                }
                 // chunks whose junction check failed are redone literally, one wave per chunk (all others exit at once)
                 gate = kb.flags;
                 FDCM_K2(64, 8, 4, false);

@@ -4,10 +4,22 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <numeric>
 #include <thread>
 
 #include "fdcm_internal.h"
+
+namespace fdcm {
+int device_cus(int device) {
+    static std::mutex mu;
+    static int cached[64] = {};
+    std::lock_guard<std::mutex> lock(mu);
+    int& c = cached[device & 63];
+    if (c <= 0) FDCM_HIP(hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, device));
+    return c;
+}
+}  // namespace fdcm
 
 namespace fdcm {
 const char* last_error_cstr();

@@ -110,6 +110,7 @@ struct fdcm_featuremap {
     int distance = 0;
     bool bitmap_clean = false;   // k_coldesc left the seed bitmap zeroed (it clears what it reads)
     long bitmap_words = 0;       // size the bitmap had then
+    long k2_cost_chunks = 0; int k2_cost_w = 0;  // the L2 sweep's per-chunk costs in `stack` are those of a build with this shape
     int off_m = 0, off_steps = 0;  // the group table in `offtab` is valid for this depth and feature width
     bool build_pending = false;  // the last build is queued on `stream` but has not been waited for
     float build_host_ms = 0.f;   // host time of that call up to its first kernel launch
@@ -184,6 +185,8 @@ inline unsigned ordered_key_host(float f) {
     __builtin_memcpy(&u, &f, 4);
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
+// compute units of a device (cached; fdcm_capi.cpp)
+int device_cus(int device);
 // pooled pinned host buffers for match arrays returned to the caller (fdcm_host.cpp)
 fdcm_match* result_acquire(size_t bytes);
 void result_release(fdcm_match* m);

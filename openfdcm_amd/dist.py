@@ -8,11 +8,19 @@ rank order reproduces the reference's positional order (defaultmatch.cpp:51-86) 
 ranges are contiguous.  Backend "nccl" is RCCL on ROCm; "gloo" runs the same code on CPU tensors
 (used by the CPU tests with a stand-in search function).
 """
-import numpy as np
-import torch
-import torch.distributed as dist
+import sys
 
+import numpy as np
+
+from . import _capi
 from ._capi import MATCH_DTYPE
+
+if _capi.loaded() and "torch" not in sys.modules:
+    # torch bundles its own HIP runtime; imported after libfdcm_hip.so (which brought /opt/rocm's) it finds no device
+    raise ImportError("import torch (or openfdcm_amd.dist) before the first openfdcm_amd call that loads libfdcm_hip.so: "
+                      "with the library loaded first, torch's HIP runtime reports no GPU")
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 RECORD_BYTES = MATCH_DTYPE.itemsize  # 32
 

@@ -1,6 +1,14 @@
 import os
 import sys
 
+# torch bundles its own HIP runtime; when libfdcm_hip.so (linked against /opt/rocm's) is loaded first, a later
+# `import torch` in the same process finds no device.  Tests that hand torch device buffers to the library need both,
+# so torch comes first whatever the collection order.
+try:
+    import torch  # noqa: F401
+except Exception:  # not needed by the tests that do not use it
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:

@@ -543,6 +543,19 @@ def test_randomised_cases(amd, env, cases, seed):
     assert out.returncode == 0 and f"{cases} random cases identical" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
 
+@pytest.mark.parametrize("env", [{}, {"FDCM_K2_LPT": "1"}], ids=["default", "launch-order-from-history"])
+def test_rebuilds_of_one_handle(amd, env):
+    """A handle rebuilt over scenes of changing content and size (tools/rebuild_parity.py): every volume bit for bit.
+    The second variant forces the L2 sweep's launch order by the previous build's chunk times at these small sizes."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "rebuild_parity.py"), "8", "3"],
+                         capture_output=True, text=True, timeout=600, env={**os.environ, **env})
+    assert out.returncode == 0 and "24 rebuilds identical" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
 def test_frame_pipeline_reports_a_failed_frame_and_keeps_going(amd):
     """A frame whose build fails (feature size above the supported maximum) is reported by its wait();
     the slot stays usable."""
