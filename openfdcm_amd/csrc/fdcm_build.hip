@@ -562,19 +562,27 @@ __device__ __forceinline__ void env_phase(const ColDesc* __restrict__ desc, int 
             const float dx = (float)(wd * 64 + lane - x);
             unsigned long long mk = __ballot(lb * lb + dx * dx <= bound) & seeded;
             while (mk) {
-                const int j = __ffsll((long long)mk) - 1;
+                // two columns per round: their evaluations do not depend on each other, so the instructions of one fill
+                // the issue gaps of the other (a lone wave issues a dependent instruction every ~7 cycles).  The last
+                // column of an odd count is evaluated twice, which changes nothing (ties go to the smaller column).
+                const int j1 = __ffsll((long long)mk) - 1;
                 mk &= mk - 1ull;
-                const int u = wd * 64 + j;
-                unsigned long long wc;
-                int pc, nc;
-                desc_lane4(dv, j, wc, pc, nc);
-                const float fu = column_value<true>(wc, pc, nc, lane, y);
-                const int du = u - x;
-                const float val = fu + (float)(du * du);
-                const bool better = val < best || (val == best && u < bestu);
-                best = better ? val : best;
-                bestu = better ? u : bestu;
-                if (DBG) ++n_eval;
+                const int j2 = mk ? __ffsll((long long)mk) - 1 : j1;
+                mk &= mk - 1ull;
+                unsigned long long wc1, wc2;
+                int pc1, nc1, pc2, nc2;
+                desc_lane4(dv, j1, wc1, pc1, nc1);
+                desc_lane4(dv, j2, wc2, pc2, nc2);
+                const int u1 = wd * 64 + j1, u2 = wd * 64 + j2, du1 = u1 - x, du2 = u2 - x;
+                const float val1 = column_value<true>(wc1, pc1, nc1, lane, y) + (float)(du1 * du1);
+                const float val2 = column_value<true>(wc2, pc2, nc2, lane, y) + (float)(du2 * du2);
+                const bool b1 = val1 < best || (val1 == best && u1 < bestu);
+                best = b1 ? val1 : best;
+                bestu = b1 ? u1 : bestu;
+                const bool b2 = val2 < best || (val2 == best && u2 < bestu);
+                best = b2 ? val2 : best;
+                bestu = b2 ? u2 : bestu;
+                if (DBG) n_eval += 2;
             }
         };
         const int wi = x >> 6;
