@@ -973,7 +973,11 @@ __device__ __forceinline__ void fill_phase(float* __restrict__ vol, int W, int H
 template <int C, int NT, bool DBG>
 __global__ void __launch_bounds__(NT) k_sweep(const ColDesc* __restrict__ desc, float* __restrict__ vol, int W, int H, int HW64,
                                               int S, int part_w, K2Buf B, int force_mod, int expm) {
-    constexpr int KL = 64, NB = 16, RE = 16;
+    // KL: owner entries per row kept in LDS for the look-ups (32: 0.47 instead of 0.43 ms at config 2, the look-ups
+    // behind the window go to HBM); NB: stack entries per row and batch of the walk (16: 140 instead of 98 VGPRs).
+    // 42 KB of LDS: three blocks per CU.  (With the mask and the junction columns moved into the pool's tail a fourth
+    // fits; config 3 then takes 1.11 instead of 1.03 ms: the waves are latency bound and slow one another down.)
+    constexpr int KL = 64, NB = 8, RE = 16;
     // one LDS pool for the three phases: the construction's ring, the addend pass's lists, the fill's staging
     constexpr size_t kPoolBytes = std::max({(size_t)C * NT * sizeof(float4), (size_t)(2 * KL + 3 * NB) * 64 * 4, (size_t)2 * RE * 256 * 4});
     __shared__ unsigned long long smask[256];
