@@ -170,7 +170,7 @@ def main():
     stage_keys = ("seeds_ms", "pass1_ms", "pass2_ms", "propagate_ms", "integral_ms", "total_ms")
     stage_ms = {k: 0.0 for k in stage_keys}
     acc = {"search_kernel_ms": 0.0, "search_total_ms": 0.0, "frames": 0, "n_matches": 0, "evaluations": 0, "last": None}
-    submit_t, latency = [], []
+    submit_t, latency, frame_log = [], [], []  # frame_log: (latency, build span, search span, search kernels) in ms
 
     def run_frames(n, record):
         """n frames through the pipeline: at most F in flight, collected in submission order."""
@@ -188,6 +188,7 @@ def main():
         if record:
             latency.append(time.perf_counter() - t_sub)
             bt, stt = pipe.pipe.last_build_timing, pipe.pipe.last_search_timing
+            frame_log.append((latency[-1] * 1e3, bt["total_ms"], stt["total_ms"], stt["kernel_ms"]))
             for k in stage_ms:
                 stage_ms[k] += bt[k]
             acc["search_kernel_ms"] += stt["kernel_ms"]
@@ -269,7 +270,11 @@ def main():
                        "parallelism": f"template shards x{world}, DT3 replicated, 1 RCCL gather per frame",
                        "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES")},
             "frame_latency_ms": {"p50": float(np.percentile(lat, 50)), "p95": float(np.percentile(lat, 95)),
-                                 "max": float(lat.max()), "note": "submit -> matches on the host, F frames in flight"},
+                                 "max": float(lat.max()), "note": "submit -> matches on the host, F frames in flight",
+                                 # the slowest frame: its position and what its GPU spans were (a stalled host shows
+                                 # normal spans, a stalled GPU a long one)
+                                 "slowest": (lambda i: {"frame": int(i), "latency": frame_log[i][0], "build_span": frame_log[i][1],
+                                                        "search_span": frame_log[i][2], "search_kernels": frame_log[i][3]})(int(np.argmax(lat)))},
             "templates_per_s": per_gpu * world * K / elapsed,
             "dt3_build_ms": avg["total_ms"], "search_ms": acc["search_total_ms"] / K,
             "in_timed_region": {"note": f"per-launch HIP-event times with {F} frames in flight: launches of concurrent "

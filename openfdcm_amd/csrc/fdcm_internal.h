@@ -148,6 +148,7 @@ struct fdcm_featuremap {
     int64_t last_n_out = 0; // matches of the last host-output search, still in s_out
     fdcm::DevBuf s_counter;
     fdcm::PinnedBuf s_stage;
+    fdcm::PinnedBuf s_cnt;   // the search's counters, written by k_scatter (device-output searches)
     fdcm::Timing timing;
     fdcm_build_timing last_build = {};
     fdcm_search_timing last_search = {};

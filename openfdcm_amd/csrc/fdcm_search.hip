@@ -535,7 +535,8 @@ __global__ void __launch_bounds__(256) k_chunk_counts(const int* __restrict__ fl
 __global__ void __launch_bounds__(1024) k_scatter(const fdcm_match* __restrict__ records, const int* __restrict__ flags,
                                                   long long n, const int* __restrict__ counts,
                                                   const int* __restrict__ evsums, int nchunks,
-                                                  fdcm_match* __restrict__ out, unsigned long long* __restrict__ counters) {
+                                                  fdcm_match* __restrict__ out, unsigned long long* __restrict__ counters,
+                                                  fdcm_match* __restrict__ out2, unsigned long long* __restrict__ counters2) {
     __shared__ long long wsum[16];
     __shared__ long long chunk_base;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -562,9 +563,16 @@ __global__ void __launch_bounds__(1024) k_scatter(const fdcm_match* __restrict__
     __syncthreads();
     long long wbase = 0;
     for (int w = 0; w < wave; ++w) wbase += wsum[w];
-    if (f) out[chunk_base + wbase + incl - 1] = records[i];
+    if (f) {
+        const fdcm_match r = records[i];
+        out[chunk_base + wbase + incl - 1] = r;
+        if (out2) out2[chunk_base + wbase + incl - 1] = r;  // pinned host memory: the caller's copy, written in place
+    }
     if ((int)blockIdx.x == nchunks - 1) {
-        if (tid == 1023) counters[2] = (unsigned long long)(chunk_base + wbase + incl);
+        if (tid == 1023) {
+            counters[2] = (unsigned long long)(chunk_base + wbase + incl);
+            if (counters2) counters2[2] = (unsigned long long)(chunk_base + wbase + incl);
+        }
         long long ev = 0;
         for (int i2 = tid; i2 < nchunks; i2 += 1024) ev += evsums[i2];
         for (int d = 32; d >= 1; d >>= 1) ev += __shfl_xor(ev, d);
@@ -575,6 +583,7 @@ __global__ void __launch_bounds__(1024) k_scatter(const fdcm_match* __restrict__
             long long tot = 0;
             for (int w = 0; w < 16; ++w) tot += wsum[w];
             counters[0] = (unsigned long long)tot;
+            if (counters2) counters2[0] = (unsigned long long)tot;
         }
     }
 }
@@ -738,25 +747,29 @@ void run_search(fdcm_featuremap* fm, const fdcm_templates* t, const float* scene
     }
     int* d_counts = P.flags + ncand;
     int* d_evsums = P.evals + ncand;
+    // The matches (host-output search) and the counters reach the host without a copy command: k_scatter writes them
+    // into pinned host memory itself.  (A hipMemcpyAsync behind the kernels stalled for 8 - 12 ms about once per 100 ms
+    // of running; the kernels before it and the build were on time.)
+    fdcm_match* host_out = nullptr;
+    unsigned long long* host_cnt = nullptr;
+    if (out_host) {
+        *out_host = result_acquire((size_t)(ncand + 1) * sizeof(fdcm_match));
+        FDCM_HIP(hipHostGetDevicePointer((void**)&host_out, *out_host, 0));
+        host_cnt = reinterpret_cast<unsigned long long*>(host_out + ncand);
+    } else {
+        fm->s_cnt.reserve(64);
+        FDCM_HIP(hipHostGetDevicePointer((void**)&host_cnt, fm->s_cnt.p, 0));
+    }
     hipLaunchKernelGGL(k_chunk_counts, dim3((unsigned)nchunks), dim3(256), 0, st, P.flags, P.evals, ncand, d_counts, d_evsums);
     hipLaunchKernelGGL(k_scatter, dim3((unsigned)nchunks), dim3(1024), 0, st, P.records, P.flags, ncand, d_counts, d_evsums,
-                       nchunks, dst, P.counters);
+                       nchunks, dst, P.counters, host_out, host_cnt);
     FDCM_HIP(hipEventRecord(ev[7], st));
     FDCM_HIP(hipGetLastError());
     unsigned long long hc[3] = {0, 0, 0};
-    if (out_host) {
-        // host-output search: the count is not known on the host yet, so the whole candidate capacity
-        // (32 B per candidate, plus the counter record) goes to the caller's (pooled, pinned) buffer in the
-        // same stream: one copy, one synchronisation per search
-        *out_host = result_acquire((size_t)(ncand + 1) * sizeof(fdcm_match));
-        FDCM_HIP(hipMemcpyAsync(*out_host, dst, (size_t)(ncand + 1) * sizeof(fdcm_match), hipMemcpyDeviceToHost, st));
-    } else {
-        FDCM_HIP(hipMemcpyAsync(hc, P.counters, sizeof hc, hipMemcpyDeviceToHost, st));
-    }
     FDCM_HIP(hipEventRecord(ev[8], st));
     FDCM_HIP(hipStreamSynchronize(st));
     finish_build(fm);  // a build queued before this search is complete as well: collect its timings
-    if (out_host) std::memcpy(hc, *out_host + ncand, sizeof hc);
+    std::memcpy(hc, out_host ? (const void*)(*out_host + ncand) : (const void*)fm->s_cnt.p, sizeof hc);
     *n_out = (int64_t)hc[2];
     fm->last_search.evaluations = (int64_t)hc[0];
     FDCM_HIP(hipEventElapsedTime(&fm->last_search.kernel_ms, ev[6], ev[7]));
