@@ -142,6 +142,14 @@ int fdcm_search_device(const fdcm_featuremap* fm, const fdcm_templates* template
                        int64_t batch_size, int32_t tmpl_index_base, fdcm_match* out_device, int64_t* n_out);
 int fdcm_search_last_timing(const fdcm_featuremap* fm, fdcm_search_timing* t);
 void fdcm_matches_free(fdcm_match* m); /* match arrays are pinned host buffers from a pool inside the library */
+/* Concatenate the valid records of n_blocks fixed-capacity blocks that sit back to back in device memory into a
+ * library-owned host array, in block order.  A block is capacity_records + 1 records; the first int64 of its last
+ * record holds its record count -- what a gather of fdcm_search_device outputs assembles when every rank appends its
+ * count that way (openfdcm_amd/dist.py).  Queued on `stream` (a hipStream_t of the current device, NULL = the default
+ * stream) behind whatever filled the blocks there; returns when the array is complete (a kernel writes it into pinned
+ * memory: no copy command).  Release with fdcm_matches_free. */
+int fdcm_blocks_to_host(const void* blocks_device, int32_t n_blocks, int64_t capacity_records, void* stream,
+                        fdcm_match** out, int64_t* n_out);
 
 /* ---- template shards over several GPUs of one node, from ONE process (the reference's own
  *      parallel seam is the per-candidate task loop, batchoptimize.cpp:102-114) ----

@@ -66,6 +66,7 @@ SYMBOLS = [
                                      _vp, _i64p]),
     ("fdcm_search_last_timing", C.c_int, [_vp, C.POINTER(SearchTiming)]),
     ("fdcm_matches_free", None, [_vp]),
+    ("fdcm_blocks_to_host", C.c_int, [_vp, C.c_int32, C.c_int64, _vp, C.POINTER(_vp), C.POINTER(C.c_int64)]),
     ("fdcm_topk", C.c_int, [_vp, _vp, _vp, C.c_int64, C.c_int32, C.c_int, C.c_float, C.c_int64, C.POINTER(_vp), _i64p]),
     ("fdcm_pipeline_create", C.c_int, [C.c_int64, C.c_float, C.c_float, C.c_int, _vp, C.c_int64, C.c_int64, C.c_int,
                                        C.c_int64, C.c_int32, C.c_int, C.POINTER(_vp)]),

@@ -405,6 +405,21 @@ int fdcm_search_last_timing(const fdcm_featuremap* fm, fdcm_search_timing* t) {
 
 void fdcm_matches_free(fdcm_match* m) { result_release(m); }
 
+int fdcm_blocks_to_host(const void* blocks_device, int32_t n_blocks, int64_t capacity_records, void* stream, fdcm_match** out,
+                        int64_t* n_out) {
+    if (out) *out = nullptr;
+    if (n_out) *n_out = 0;
+    int rc = guarded([&] {
+        require(out && n_out && n_blocks >= 0 && capacity_records >= 0 && (n_blocks == 0 || blocks_device), "bad arguments");
+        require((int64_t)n_blocks * capacity_records < (int64_t)1 << 40, "too many records");
+        FDCM_HIP(hipSetDevice(g_device));
+        if (n_blocks == 0 || capacity_records == 0) { *out = result_acquire(64); return; }
+        blocks_to_host((hipStream_t)stream, blocks_device, n_blocks, capacity_records, out, n_out);
+    });
+    if (rc != FDCM_OK && out && *out) { result_release(*out); *out = nullptr; }
+    return rc;
+}
+
 int fdcm_filter_in_range(const float* lines, int64_t n_lines, const float center[2], float low_boundary,
                          float high_boundary, int64_t* out_indices, int64_t* n_out) {
     return guarded([&] {

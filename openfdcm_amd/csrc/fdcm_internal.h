@@ -180,6 +180,10 @@ void run_topk(fdcm_featuremap* fm, const fdcm_templates* t, const fdcm_match* ma
               int penalty, float tau, int64_t k, fdcm_match** out, int64_t* n_out);
 void run_topk_device(fdcm_featuremap* fm, const fdcm_templates* t, const fdcm_match* matches_device, int64_t n, int32_t base,
                      int penalty, float tau, int64_t k, fdcm_match* out_device);
+// records to the host without a copy command (a kernel writes into the mapped pinned destination); queued on st
+void records_to_host(hipStream_t st, const fdcm_match* src_device, int64_t n, fdcm_match* dst_pinned);
+// the valid records of n_blocks fixed-capacity blocks (count in the trailing record) into a pooled pinned array; waits for st
+void blocks_to_host(hipStream_t st, const void* blocks_device, int32_t n_blocks, int64_t cap, fdcm_match** out, int64_t* n_out);
 // the device tail's total order on float bit patterns (-0 < +0, NaNs at the ends), for host-side merges
 inline unsigned ordered_key_host(float f) {
     unsigned u;

@@ -227,7 +227,7 @@ fdcm_match* download(fdcm_sharded* s, int64_t total) {
     try {
         FDCM_HIP(hipSetDevice(root.device));
         if (total) {
-            FDCM_HIP(hipMemcpyAsync(out, s->gathered.p, (size_t)total * sizeof(fdcm_match), hipMemcpyDeviceToHost, root.stream));
+            records_to_host(root.stream, s->gathered.as<fdcm_match>(), total, out);
             FDCM_HIP(hipStreamSynchronize(root.stream));
         }
     } catch (...) {

@@ -10,6 +10,7 @@
 // (the reference's std::sort leaves ties unspecified): a stable radix sort of (score, position) with rocPRIM.
 #include <rocprim/device/device_radix_sort.hpp>
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 
@@ -44,6 +45,54 @@ __global__ void k_tail_gather(const fdcm_match* __restrict__ m, const unsigned* 
     fdcm_match r = m[idx[j]];
     r.score = pscore[idx[j]];
     out[j] = r;
+}
+
+// Records to the host without a copy command: a kernel writes them into mapped pinned memory (a hipMemcpyAsync
+// device -> host behind a stream's kernels completed 8 - 12 ms late now and then on this system; kernels never did).
+__global__ void __launch_bounds__(256) k_records_to_host(const uint4* __restrict__ src, long long n16, uint4* __restrict__ dst) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long long)gridDim.x * 256) dst[i] = src[i];
+}
+void records_to_host(hipStream_t st, const fdcm_match* src_device, int64_t n, fdcm_match* dst_pinned) {
+    if (n <= 0) return;
+    fdcm_match* dst_dev = nullptr;
+    FDCM_HIP(hipHostGetDevicePointer((void**)&dst_dev, dst_pinned, 0));
+    const long long n16 = (long long)n * (long long)(sizeof(fdcm_match) / 16);
+    hipLaunchKernelGGL(k_records_to_host, dim3((unsigned)std::min<long long>((n16 + 255) / 256, 2048)), dim3(256), 0, st,
+                       reinterpret_cast<const uint4*>(src_device), n16, reinterpret_cast<uint4*>(dst_dev));
+    FDCM_HIP(hipGetLastError());
+}
+
+// n_blocks blocks of (cap + 1) records back to back, the first int64 of a block's last record = its record count:
+// the valid records of all blocks, in block order, into out (mapped pinned memory); total behind them at out[n_blocks * cap].
+__global__ void __launch_bounds__(256) k_blocks_to_host(const uint4* __restrict__ blocks, int n_blocks, long long cap,
+                                                        uint4* __restrict__ out) {
+    const int b = blockIdx.y;
+    const long long units = 2 * (cap + 1);  // 16-byte units per block
+    long long before = 0, mine = 0, total = 0;
+    for (int i = 0; i < n_blocks; ++i) {
+        long long c = reinterpret_cast<const long long*>(blocks + (long long)i * units + 2 * cap)[0];
+        c = c < 0 ? 0 : (c > cap ? cap : c);
+        if (i < b) before += c;
+        if (i == b) mine = c;
+        total += c;
+    }
+    const uint4* src = blocks + (long long)b * units;
+    uint4* dst = out + 2 * before;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < 2 * mine; i += (long long)gridDim.x * 256) dst[i] = src[i];
+    if (b == 0 && blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<long long*>(out + 2 * (long long)n_blocks * cap)[0] = total;
+}
+void blocks_to_host(hipStream_t st, const void* blocks_device, int32_t n_blocks, int64_t cap, fdcm_match** out, int64_t* n_out) {
+    *out = result_acquire(((size_t)n_blocks * (size_t)cap + 1) * sizeof(fdcm_match));
+    fdcm_match* dst_dev = nullptr;
+    FDCM_HIP(hipHostGetDevicePointer((void**)&dst_dev, *out, 0));
+    const unsigned gx = (unsigned)std::min<long long>((2 * cap + 255) / 256 + 1, 256);
+    hipLaunchKernelGGL(k_blocks_to_host, dim3(gx, (unsigned)n_blocks), dim3(256), 0, st, reinterpret_cast<const uint4*>(blocks_device),
+                       (int)n_blocks, (long long)cap, reinterpret_cast<uint4*>(dst_dev));
+    FDCM_HIP(hipGetLastError());
+    FDCM_HIP(hipStreamSynchronize(st));
+    long long total = 0;
+    std::memcpy(&total, *out + (size_t)n_blocks * (size_t)cap, sizeof total);
+    *n_out = total;
 }
 
 // The k best of n device-resident matches, penalised, into out_device (k <= n, both on fm's device); returns when
@@ -103,7 +152,7 @@ void run_topk(fdcm_featuremap* fm, const fdcm_templates* t, const fdcm_match* ma
     if (k == 0) return;
     fm->s_tail_out.reserve((size_t)k * sizeof(fdcm_match));
     run_topk_device(fm, t, matches_device, n, base, penalty, tau, k, fm->s_tail_out.as<fdcm_match>());
-    FDCM_HIP(hipMemcpyAsync(*out, fm->s_tail_out.p, (size_t)k * sizeof(fdcm_match), hipMemcpyDeviceToHost, fm->stream));
+    records_to_host(fm->stream, fm->s_tail_out.as<fdcm_match>(), k, *out);
     FDCM_HIP(hipStreamSynchronize(fm->stream));
     *n_out = k;
 }

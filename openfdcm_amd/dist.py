@@ -125,9 +125,9 @@ class FrameGatherer:
     the frame).  ONE collective per frame: every rank sends a fixed-capacity block whose trailing
     record carries its record count (the way fdcm_search hands matches and count to the host in one
     copy), so no count exchange precedes the gather.  Rank `dst` then reads the counts out of the
-    gathered blocks (one small download), compacts on the device and downloads the exact list.
-    Results are views into a ring of `depth` host buffers: a returned array stays valid until
-    `depth` more frames have been gathered."""
+    gathered blocks and delivers the exact list to the host: on a GPU with one library call (fdcm_blocks_to_host: a kernel
+    writes the records into pinned memory); on CPU tensors (the gloo tests) with torch copies into a ring of `depth` host
+    buffers, where a returned array stays valid until `depth` more frames have been gathered."""
 
     def __init__(self, capacity_records, device, group=None, dst=0, depth=4):
         self.group, self.dst, self.device = group, dst, device
@@ -141,10 +141,10 @@ class FrameGatherer:
             self.recv_views = list(self.recv.split(self.blk))
             # the count of rank r: first int64 of the trailing record of block r
             self.trailers = self.recv.view(torch.int64).view(self.world, self.blk // 8)[:, self.cap * RECORD_BYTES // 8]
-            self.packed = torch.empty(self.world * self.cap * RECORD_BYTES, dtype=torch.uint8, device=device)
-            self.host = [torch.empty(self.world * self.cap * RECORD_BYTES, dtype=torch.uint8, pin_memory=cuda)
-                         for _ in range(depth)]
-            self.turn = 0
+            if not cuda:  # the CPU-tensor path (gloo tests) packs and copies with torch
+                self.packed = torch.empty(self.world * self.cap * RECORD_BYTES, dtype=torch.uint8, device=device)
+                self.host = [torch.empty(self.world * self.cap * RECORD_BYTES, dtype=torch.uint8) for _ in range(depth)]
+                self.turn = 0
 
     def block_bytes(self):
         return self.blk
@@ -155,6 +155,17 @@ class FrameGatherer:
         dist.gather(block[: self.blk], self.recv_views if self.rank == self.dst else None, dst=self.dst, group=self.group)
         if self.rank != self.dst:
             return None
+        if self.device.type == "cuda":
+            # one library call on torch's stream, behind the gather: a kernel reads the blocks' counts and writes the
+            # valid records of all blocks, in rank order, into a pinned host array (no copy commands, one
+            # synchronisation); the array is library-owned and stays valid as long as it is referenced
+            import ctypes as C
+            from .engine import _adopt_matches
+            out, n = C.c_void_p(), C.c_int64()
+            _capi.check(_capi.lib().fdcm_blocks_to_host(C.c_void_p(self.recv.data_ptr()), self.world, self.cap,
+                                                        C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream),
+                                                        C.byref(out), C.byref(n)))
+            return _adopt_matches(out, n.value)
         self.counts_host.copy_(self.trailers, non_blocking=True)
         if self.device.type == "cuda":
             torch.cuda.current_stream(self.device).synchronize()  # counts on the host (the gather is queued before)
