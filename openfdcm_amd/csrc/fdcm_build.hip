@@ -122,6 +122,49 @@ __global__ void __launch_bounds__(256) k_coldesc(unsigned long long* __restrict_
     }
 }
 
+// The same for H <= 4096 (one group of words per column), with coalesced stores: a block takes 64 neighbouring
+// columns of a slice, SEG lanes (16 / 32 / 64: the words of a column) scan one column each, 64 / SEG columns per wave
+// pass, and the descriptors go through LDS so that every store covers the block's columns of one chunk (1 KB or 512 B
+// contiguous; the wave-per-column kernel writes 16 bytes every W * 16).
+template <int SEG, int XT>  // XT columns per block: 64, or 32 when a column has 64 words (32 KB of LDS instead of 64)
+__global__ void __launch_bounds__(256) k_coldesc_tile(unsigned long long* __restrict__ bitmap, ColDesc* __restrict__ desc,
+                                                      int W, int HW64) {
+    extern __shared__ uint4 tile[];  // [word][XT columns], rows padded by one unit (bank spread)
+    constexpr int STR = XT + 1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wi = lane & (SEG - 1), ci = lane / SEG;
+    constexpr int CPP = 64 / SEG, CPW = XT / 4;  // columns per wave pass, columns per wave
+    const long k = blockIdx.y;
+    const int x0 = blockIdx.x * XT;
+    for (int pass = 0; pass < CPW / CPP; ++pass) {
+        const int xl = wave * CPW + pass * CPP + ci, x = x0 + xl;
+        const bool valid = x < W && wi < HW64;
+        unsigned long long* bw = bitmap + ((size_t)k * W + (size_t)min(x, W - 1)) * HW64;
+        const unsigned long long word = valid ? bw[wi] : 0ull;
+        if (word) bw[wi] = 0ull;
+        const int last_i = word ? wi * 64 + 63 - __clzll(word) : INT_MIN;
+        const int first_i = word ? wi * 64 + (__ffsll((long long)word) - 1) : INT_MAX;
+        int pmax = last_i, smin = first_i;  // inclusive scans inside the SEG lanes of a column
+#pragma unroll
+        for (int d = 1; d < SEG; d <<= 1) {
+            const int a = __shfl_up(pmax, d), b = __shfl_down(smin, d);
+            if (wi >= d) pmax = max(pmax, a);
+            if (wi + d < SEG) smin = min(smin, b);
+        }
+        const int pe = __shfl_up(pmax, 1), se = __shfl_down(smin, 1);
+        const int pv = wi == 0 ? INT_MIN : pe, nx = wi == SEG - 1 ? INT_MAX : se;
+        if (wi < HW64)
+            tile[wi * STR + xl] = make_uint4((unsigned)(word & 0xffffffffull), (unsigned)(word >> 32),
+                                             (unsigned)(pv == INT_MIN ? -kFar : pv), (unsigned)(nx == INT_MAX ? kFar : nx));
+    }
+    __syncthreads();
+    uint4* out = reinterpret_cast<uint4*>(desc);
+    for (int idx = threadIdx.x; idx < HW64 * XT; idx += 256) {
+        const int w = idx / XT, xl = idx - w * XT;
+        if (x0 + xl < W) out[((size_t)k * HW64 + w) * W + x0 + xl] = tile[w * STR + xl];
+    }
+}
+
 // Pass 1 of distanceTransform (imgproc.h:178 / :186, along y) evaluated on the fly.  On a
 // 0 / FLT_MAX image the lower-envelope pass yields exactly the squared distance to the nearest
 // seed of the column (every envelope owner is a seed and owns itself), or FLT_MAX for a seedless
@@ -1590,8 +1633,18 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after) {
                            fm->bitmap.as<unsigned long long>(), W, H, HW64);
     FDCM_HIP(hipEventRecord(ev[1], st));
     ColDesc* d_desc = fm->coldesc.as<ColDesc>();
-    hipLaunchKernelGGL(k_coldesc, dim3((unsigned)((ncols + 3) / 4)), dim3(256), 0, st,
-                       fm->bitmap.as<unsigned long long>(), d_desc, W, HW64, ncols);
+    if (HW64 <= 64) {
+        unsigned long long* bm = fm->bitmap.as<unsigned long long>();
+        const int XT = HW64 > 32 ? 32 : 64;
+        const dim3 grid((unsigned)((W + XT - 1) / XT), (unsigned)m);
+        const size_t lds = (size_t)HW64 * (XT + 1) * sizeof(uint4);
+        if (HW64 <= 16) hipLaunchKernelGGL((k_coldesc_tile<16, 64>), grid, dim3(256), lds, st, bm, d_desc, W, HW64);
+        else if (HW64 <= 32) hipLaunchKernelGGL((k_coldesc_tile<32, 64>), grid, dim3(256), lds, st, bm, d_desc, W, HW64);
+        else hipLaunchKernelGGL((k_coldesc_tile<64, 32>), grid, dim3(256), lds, st, bm, d_desc, W, HW64);
+    } else {
+        hipLaunchKernelGGL(k_coldesc, dim3((unsigned)((ncols + 3) / 4)), dim3(256), 0, st,
+                           fm->bitmap.as<unsigned long long>(), d_desc, W, HW64, ncols);
+    }
     if (HW64 <= 64) { fm->bitmap_clean = true; fm->bitmap_words = bitmap_words; }  // one group of words per column: cleared in place
     FDCM_HIP(hipEventRecord(ev[2], st));
     {
