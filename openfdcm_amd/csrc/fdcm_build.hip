@@ -1,18 +1,20 @@
 // fdcm_build.hip -- DT3 feature-map build on gfx950 (buildCpuFeaturemap<D>, dt3cpu.h:174-234).
 //
-// Volume layout in HBM: float vol[k][x][y] (y fastest) -- per slice exactly the reference's
-// RawImage<float>(H, W) column-major (math.h:57), so a slice read-back is one memcpy.
+// Volume layout in HBM: the sweeps write float vol[k][x][y] (y fastest: the reference's RawImage<float>(H, W)
+// column-major, math.h:57); the propagation moves it into the interleaved layout [k][x/4][y][x%4] (ivol_index,
+// fdcm_internal.h) that the line integral and the search work on.
 //
 // Kernels (W x H = feature size, m = slices, V = 4*m*W*H bytes):
-//   K0 k_seeds      clipped scene lines -> seed bitmap (1 bit per pixel, bits along y)   ~V/32
-//   K1 k_coldesc    per column and 64-row chunk: seed bits + nearest seed before/after   ~V/16
-//   K2 k_pass2_l2   pass 1 (from descriptors) fused into the literal in-place lower-envelope
-//                   pass along x (imgproc.h:91-130)                                      write V
-//      k_l1_*       L1: forward sweep from descriptors (write V), backward sweep (read V, write V)
+//   K0 k_seeds          clipped scene lines -> seed bitmap (1 bit per pixel, bits along y)   ~V/32
+//   K1 k_coldesc_tile   per column and 64-row chunk: seed bits + nearest seed before/after   ~V/16
+//   K2 k_sweep          L2 / L2^2: pass 1 (from descriptors) fused into the literal in-place lower-envelope pass
+//                       along x (imgproc.h:91-130), rows cut into verified segments; k_pass2_l2: the
+//                       one-wave-per-chunk form (redo path, FDCM_K2_LEGACY)                   write V
+//      k_l1_*           L1: forward sweep from descriptors (write V), backward sweep (read V, write V)
 //   K3 k_propagate_reg<M> / k_propagate   orientation propagation, 4m steps per pixel in
-//                   registers (generic depth: LDS) (+ sqrt for L2)                       read V, write V
-//   K4 k_integral   directional prefix sum per slice, one sequential float chain per lane;
-//                   shallow and steep sweeps (the latter through LDS tiles) in one launch  read V, write V
+//                       registers (generic depth: LDS) (+ sqrt for L2)                        read V, write V
+//   K4 k_integral       directional prefix sum per slice, one sequential float chain per row / column of 16-byte
+//                       units; shallow and steep sweeps (the latter through LDS tiles) in one launch  read V, write V
 // Compiled with -ffp-contract=off; divide and sqrt are the correctly rounded forms.
 #include <algorithm>
 #include <chrono>

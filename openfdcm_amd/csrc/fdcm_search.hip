@@ -8,10 +8,11 @@
 // builds its candidate itself -- align(), transform(), orientation bins with the glibc atanf
 // restatement, bounding box, rasterizeVector, minmaxTranslation -- and replays the optimiser.
 // Results go to a positional record/flag/evaluation-count slot per candidate (no atomics);
-// k_chunk_counts + k_scatter compact them in the reference's order.
+// k_chunk_counts + k_scatter compact them in the reference's order -- for a host-output search straight into the
+// caller's pinned buffer (no copy command: see run_search).
 //
-// Scoring is the gather-bound part: sum_i |I[bin_i](p1_i + t) - I[bin_i](p2_i + t)| with two
-// 4-byte gathers per line from the DT3 volume.  Two lanes share one translation (the two packet
+// Scoring: sum_i |I[bin_i](p1_i + t) - I[bin_i](p2_i + t)| with two 4-byte gathers per line from the integrated
+// volume, whose interleaved layout (ivol_index) puts 4 x 4 pixels into a 64-byte sector.  Two lanes share one translation (the two packet
 // accumulators of Eigen's VectorXf::sum()), so one round scores up to 32 translations with all
 // gathers of a lane in flight together.  The first round scores translation 0 and the first
 // WIN multipliers of BOTH directions; the reference's exit rule (batches, the un-reset
