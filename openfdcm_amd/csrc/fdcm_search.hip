@@ -167,19 +167,19 @@ struct OptState {
     bool reset_back;  // IndulgentOptimize: the negative direction compares against the initial score again
     size_t W, H;  // W: floats per slice of the interleaved volume (ivol_slice_floats)
     float tx, ty, savx, savy;
-    long long lim_p, lim_n;
+    int lim_p, lim_n;  // multiplier limits: 32 bits are enough, see k_search
 };
 
 // Score multipliers k_from, k_from + dir, ... (cnt of them) into sc[dst ..]; with_zero additionally
 // scores translation (0,0) into sc[2 WIN].  32 translations per gather round.
-__device__ __forceinline__ void score_range(const float* __restrict__ vol, const OptState& o, int dir, long long k_from,
+__device__ __forceinline__ void score_range(const float* __restrict__ vol, const OptState& o, int dir, int k_from,
                                             int cnt, int dst, bool with_zero) {
     const int h = o.lane >> 5, slot = o.lane & 31;  // neighbouring lanes = neighbouring translations
     const int total = cnt + (with_zero ? 1 : 0);
     for (int s0 = 0; s0 < total; s0 += 32) {
         const int idx = s0 + slot - (with_zero ? 1 : 0);  // -1 = the zero translation
         const bool act = idx < cnt;
-        const long long k = idx < 0 ? 0 : k_from + (long long)dir * idx;
+        const int k = idx < 0 ? 0 : k_from + dir * idx;
         // translation = float(k) * scaled_align_vec (:58/:81); Point2{0,0} for the initial score (:36)
         const float trx = idx < 0 ? 0.f : (float)k * o.savx, try_ = idx < 0 ? 0.f : (float)k * o.savy;
         const float s = pair_score(vol, o.L, o.n_t, o.tx + trx, o.ty + try_, o.W, o.H, h, act);
@@ -192,19 +192,19 @@ __device__ __forceinline__ void score_range(const float* __restrict__ vol, const
 // the rule.  IndulgentOptimize walks like DefaultOptimize (a passed-through score is scored again at the
 // same multiplier until the allowance is used up, then the walk breaks) but starts the negative direction
 // from the initial score again.
-__device__ __forceinline__ void optimise(const float* __restrict__ vol, const OptState& o, float& best, long long& best_k,
-                                         unsigned long long& n_eval) {
+__device__ __forceinline__ void optimise(const float* __restrict__ vol, const OptState& o, float& best, int& best_k,
+                                         int& n_eval) {
     const int WIN = o.WIN, B = o.B;
     const int h = o.lane >> 5, slot = o.lane & 31;  // neighbouring lanes = neighbouring translations
     // ---- round 1: translation 0 and the first WIN multipliers of both directions
-    const int have_p = (int)min<long long>(WIN, o.lim_p >= 1 ? o.lim_p : 0);
-    const int have_n = (int)min<long long>(WIN, o.lim_n <= -1 ? -o.lim_n : 0);
+    const int have_p = min(WIN, o.lim_p >= 1 ? o.lim_p : 0);
+    const int have_n = min(WIN, o.lim_n <= -1 ? -o.lim_n : 0);
     if (1 + have_p + have_n <= 32) {
         // one gather round: slot 0 = zero, then positives, then negatives
         const int idx = slot - 1;
         const bool is_p = idx >= 0 && idx < have_p, is_n = idx >= have_p && idx < have_p + have_n;
         const bool act = slot == 0 || is_p || is_n;
-        const long long k = is_p ? 1 + idx : (is_n ? -1 - (idx - have_p) : 0);
+        const int k = is_p ? 1 + idx : (is_n ? -1 - (idx - have_p) : 0);
         const float trx = slot == 0 ? 0.f : (float)k * o.savx, try_ = slot == 0 ? 0.f : (float)k * o.savy;
         const float s = pair_score(vol, o.L, o.n_t, o.tx + trx, o.ty + try_, o.W, o.H, h, act);
         if (act && h == 0) o.sc[slot == 0 ? 2 * WIN : (is_p ? idx : WIN + (idx - have_p))] = s;
@@ -218,34 +218,38 @@ __device__ __forceinline__ void optimise(const float* __restrict__ vol, const Op
     float back = init;  // scores.back(): NOT reset between the two directions (batchoptimize.cpp:73)
     for (int dir = 1; dir >= -1; dir -= 2) {
         if (dir < 0 && o.reset_back) back = init;  // indulgentoptimize.cpp:59-63
-        const long long lim = dir > 0 ? o.lim_p : o.lim_n;
+        const int lim = dir > 0 ? o.lim_p : o.lim_n;
         const int off = dir > 0 ? 0 : WIN;
-        long long win0 = dir;                       // multiplier held in sc[off]
+        int win0 = dir;                             // multiplier held in sc[off]
         int have = dir > 0 ? have_p : have_n;       // multipliers available from win0 on
-        for (long long k0 = dir; dir > 0 ? k0 <= lim : k0 >= lim; k0 += (long long)dir * B) {
-            long long nb = dir > 0 ? (lim - k0 + 1) : (k0 - lim + 1);
+        for (int k0 = dir; dir > 0 ? k0 <= lim : k0 >= lim; k0 += dir * B) {
+            int nb = dir > 0 ? (lim - k0 + 1) : (k0 - lim + 1);
             if (nb > B) nb = B;
             // std::min_element over the batch (first minimum) and its last element, :63-70 / :86-93
             float bmin = 0.f, blast = 0.f;
-            long long bmin_k = 0;
-            for (long long c0 = 0; c0 < nb;) {
-                long long rel = dir > 0 ? (k0 + c0 - win0) : (win0 - (k0 - c0));  // index in the window
+            int bmin_k = 0;
+            for (int c0 = 0; c0 < nb;) {
+                int rel = dir > 0 ? (k0 + c0 - win0) : (win0 - (k0 - c0));  // index in the window
                 if (rel >= have) {  // the rule walks on: score the next window of this direction
                     win0 = k0 + dir * c0;
-                    const long long left = dir > 0 ? (lim - win0 + 1) : (win0 - lim + 1);
-                    have = (int)min<long long>(WIN, left);
+                    const int left = dir > 0 ? (lim - win0 + 1) : (win0 - lim + 1);
+                    have = min(WIN, left);
                     score_range(vol, o, dir, win0, have, off, false);
                     rel = 0;
                 }
-                const int take = (int)min<long long>(nb - c0, have - rel);
-                for (int e = 0; e < take; ++e) {
-                    const float s = o.sc[off + (int)rel + e];
-                    if ((c0 == 0 && e == 0) || s < bmin) { bmin = s; bmin_k = k0 + dir * (c0 + e); }
-                    blast = s;
+                const int take = min(nb - c0, have - rel);
+                // the piece's scores one per lane: its first minimum is a wave reduction, not a walk through LDS
+                for (int e0 = 0; e0 < take; e0 += 64) {
+                    const int n = min(64, take - e0);
+                    const float s = o.lane < n ? o.sc[off + rel + e0 + o.lane] : f_inf();
+                    const float mn = wave_min_f(s);
+                    const int first = __ffsll((long long)__ballot(o.lane < n && s == mn)) - 1;
+                    if ((c0 == 0 && e0 == 0) || mn < bmin) { bmin = mn; bmin_k = k0 + dir * (c0 + e0 + first); }
+                    blast = __shfl(s, n - 1);
                 }
                 c0 += take;
             }
-            n_eval += (unsigned long long)nb;
+            n_eval += nb;
             if (bmin > back) break;                 // :65 / :88
             back = bmin;                            // keep (translation, score)
             if (bmin < best) { best = bmin; best_k = bmin_k; }  // first argmin over kept scores, :97
@@ -485,8 +489,7 @@ __global__ void __launch_bounds__(256, FDCM_SEARCH_WPE) k_search(const SearchPar
         if (!f_isfinite(min_mul) || !f_isfinite(max_mul)) valid = false;  // :30-33
     }
     float best = 0.f;
-    long long best_k = 0;
-    unsigned long long n_eval = 0;
+    int best_k = 0, n_eval = 0;
     if (valid) {
         OptState o;
         o.L = L; o.sc = sc; o.n_t = n_t; o.W = ivol_slice_floats(P.W, P.H); o.H = (size_t)P.H; o.tx = P.tx; o.ty = P.ty;
@@ -494,7 +497,12 @@ __global__ void __launch_bounds__(256, FDCM_SEARCH_WPE) k_search(const SearchPar
         o.B = P.optimizer == FDCM_BATCH_OPTIMIZE ? P.batch : 1; o.WIN = P.win; o.batch_rule = P.optimizer == FDCM_BATCH_OPTIMIZE;
         o.reset_back = P.optimizer == FDCM_INDULGENT_OPTIMIZE;
         // static_cast<long>(max_mul / min_mul), batchoptimize.cpp:51,74
-        o.lim_p = (long long)max_mul; o.lim_n = (long long)min_mul;
+        // One component of the scaled align vector is exactly +-1 (rasterizeVector), so the admissible multipliers
+        // are bounded by the feature size (< 2^14): 32-bit multipliers walk exactly like the reference's longs, and
+        // float(k) is one conversion instead of a 64-bit sequence.  (The clamp only keeps the arithmetic defined.)
+        const long long lp = (long long)max_mul, ln = (long long)min_mul;
+        o.lim_p = (int)std::min<long long>(std::max<long long>(lp, -(1ll << 30)), 1ll << 30);
+        o.lim_n = (int)std::min<long long>(std::max<long long>(ln, -(1ll << 30)), 1ll << 30);
         optimise(P.vol, o, best, best_k, n_eval);
     }
     if (lane == 0) {
