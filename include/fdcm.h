@@ -113,6 +113,29 @@ int fdcm_featuremap_from_slices(const float* keys, int64_t depth, const float* v
 int fdcm_featuremap_build_staged(const float* scene_lines, int64_t n_lines, int64_t depth, float dt3_coeff,
                                  float padding, int distance, int stop_after, fdcm_featuremap** out);
 
+/* ---- the feature-map plug-in seam: what a FeatureMapInstance specialises besides getFeatureSize
+ *      (featuremap.h:27-52; FeatureMapModel<T> forwards to them, featuremap.h:80-92) and what every optimiser of the
+ *      reference calls (defaultoptimize.cpp:26,49-64, batchoptimize.cpp:27,58-62).  With these three a reference
+ *      build can wrap a handle in its own type-erased FeatureMap and run ANY of its optimisers on the HBM volume
+ *      (INTEGRATION.md).  Both are batched: one kernel launch per call. ---- */
+/* minmaxTranslation<Dt3Cpu>, dt3cpu.cpp:30-75,119-124: the admissible multiplier interval {negative, positive} of
+ * align_vec for a template (4 x n_lines, in scene coordinates: the feature map adds its scene translation itself).
+ * {inf, inf} for a zero align_vec, {NaN, NaN} when the template's bounding box starts outside the feature map. */
+int fdcm_featuremap_minmax_translation(const fdcm_featuremap* fm, const float* tmpl_lines, int64_t n_lines,
+                                       const float align_vec[2], float out_minmax[2]);
+/* the same for n_templates templates (lines concatenated, line_offsets in lines) with one align_vec each;
+ * out_minmax: 2 floats per template */
+int fdcm_featuremap_minmax_translation_batch(const fdcm_featuremap* fm, const float* tmpl_lines, const int64_t* line_offsets,
+                                             int64_t n_templates, const float* align_vecs, float* out_minmax);
+/* evaluate<Dt3Cpu>, dt3cpu.cpp:126-179: scores[t][j] = sum_i |I_bin(i)(p1_i + T + tr_j) - I_bin(i)(p2_i + T + tr_j)| for
+ * every template t and each of its translations tr_j (x, y pairs; translation_offsets in translations, n_templates + 1
+ * entries), T = the scene translation, coordinates truncated like cast<int>(), terms added in Eigen's sum() order:
+ * the reference's bits.  scores_out: one float per translation, in input order.  A translation that puts an end
+ * point outside the feature map scores NaN (the reference reads out of bounds there, dt3cpu.cpp:166-167). */
+int fdcm_featuremap_evaluate(const fdcm_featuremap* fm, const float* tmpl_lines, const int64_t* line_offsets,
+                             int64_t n_templates, const float* translations, const int64_t* translation_offsets,
+                             float* scores_out);
+
 /* ---- templates: the `templates` argument of search(), kept resident in HBM ---- */
 int fdcm_templates_create(const float* lines, const int64_t* offsets /* n_templates+1, in lines */,
                           int64_t n_templates, fdcm_templates** out);

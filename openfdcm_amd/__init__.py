@@ -94,7 +94,11 @@ class Dt3Cpu:
 
 
 class FeatureMap:
-    """Type-erased feature map (featuremap.h:98-124).  Wraps without copying the volume."""
+    """Type-erased feature map (featuremap.h:98-124).  Wraps without copying the volume.
+
+    The reference's Python module binds only the constructor and __repr__ (matching.cpp:66-70); the three
+    methods below are the C++ class's (featuremap.h:109-121), served by the HIP kernels of the seam
+    (fdcm_featuremap_minmax_translation / fdcm_featuremap_evaluate)."""
 
     def __init__(self, dt3):
         if isinstance(dt3, FeatureMap):
@@ -102,6 +106,15 @@ class FeatureMap:
         if not isinstance(dt3, Dt3Cpu):
             raise TypeError("FeatureMap expects a Dt3Cpu")
         self._dt3 = dt3
+
+    def get_feature_size(self):
+        return self._dt3.get_feature_size()
+
+    def minmax_translation(self, tmpl, align_vec):
+        return self._dt3._fm.minmax_translation(tmpl, align_vec)
+
+    def evaluate(self, templates, translations):
+        return self._dt3._fm.evaluate(templates, translations)
 
     def __repr__(self): return "<FeatureMap>"
 

@@ -55,6 +55,9 @@ SYMBOLS = [
     ("fdcm_featuremap_from_slices", C.c_int, [_fp, C.c_int64, _fp, C.c_int64, C.c_int64, _fp, C.POINTER(_vp)]),
     ("fdcm_featuremap_build_staged", C.c_int,
      [_fp, C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_int, C.c_int, C.POINTER(_vp)]),
+    ("fdcm_featuremap_minmax_translation", C.c_int, [_vp, _fp, C.c_int64, _fp, _fp]),
+    ("fdcm_featuremap_minmax_translation_batch", C.c_int, [_vp, _fp, _i64p, C.c_int64, _fp, _fp]),
+    ("fdcm_featuremap_evaluate", C.c_int, [_vp, _fp, _i64p, C.c_int64, _fp, _i64p, _fp]),
     ("fdcm_templates_create", C.c_int, [_fp, _i64p, C.c_int64, C.POINTER(_vp)]),
     ("fdcm_templates_free", C.c_int, [_vp]),
     ("fdcm_templates_count", C.c_int, [_vp, _i64p, _i64p]),

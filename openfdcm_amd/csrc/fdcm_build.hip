@@ -537,6 +537,7 @@ struct K2Buf {
     int* cost;                            // per chunk: 100 MHz ticks from the block's start to the end of its addend pass
     long NR;                              // rows of the scratch arrays (chunks * 64)
     int eslots, lslots;
+    int addend_waves;                     // waves of a block that share the addend pass (a power of two; 0 = all of them)
 };
 
 __device__ __forceinline__ unsigned long long uni64(unsigned long long v) {
@@ -1033,7 +1034,8 @@ __global__ void __launch_bounds__(NT) k_sweep(const ColDesc* __restrict__ desc, 
     __syncthreads();  // every segment's stack, count and minF are in memory
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     // the addend pass on the largest power of two of the block's waves, each with its share of the 64 rows
-    const int aw = 1 << (31 - __builtin_clz((int)blockDim.x >> 6));
+    int aw = 1 << (31 - __builtin_clz((int)blockDim.x >> 6));
+    if (B.addend_waves > 0 && B.addend_waves < aw) aw = B.addend_waves;
     if (wave < aw) {
         unsigned* w32 = reinterpret_cast<unsigned*>(pool);
         addend_phase<KL, NB, DBG>(W, S, part_w, B, force_mod, 64 / aw, reinterpret_cast<unsigned(*)[64]>(w32),
@@ -1396,21 +1398,27 @@ __device__ __forceinline__ void integral_shallow(const float* __restrict__ src, 
 // tile, and the units whose first column belongs to one of the block's first 60 chains are stored (their other
 // three columns belong to the next three chains at most: the halo).  The next tile's loads are in flight while
 // the current one is summed and stored.
-static constexpr int kStOwn = 60;
+// XC chains per block (XC / 64 waves run them), of which the first XC - 4 are the block's own: 64 while the launch is
+// small (more blocks, shorter critical path), 256 when the slices are large -- a tile is XC + drift + 4 columns wide,
+// so the columns read per column stored fall from (64 + 36) / 60 = 1.67 to (256 + 36) / 252 = 1.16, and the drift is
+// sized per slice: the chains of a slice move by at most ceil(31 |r|) + 1 columns over a tile's 32 steps, not by 32.
 template <int XC>
 __device__ __forceinline__ void integral_steep(const float* __restrict__ src, float* __restrict__ dst, int W, int H,
-                                               const IntegralDesc& d, int k) {
-    constexpr int TS = 32, TW = XC + TS + 4, NG = TW / 4, PASSES = (NG + 7) / 8;
-    __shared__ float tile[2][TW][TS + 1];
+                                               const IntegralDesc& d, int k, float* lds_tiles) {
+    constexpr int TS = 32, TW = XC + TS + 4, NG = TW / 4, PASSES = (NG + 7) / 8, OWN = XC - 4;
+    float (*tile)[TW][TS + 1] = reinterpret_cast<float (*)[TW][TS + 1]>(lds_tiles);  // [2][TW][TS + 1]
     const int steps = H, span = W, W4 = (W + 3) >> 2;
     const int last_off = (int)roundf((float)(steps - 1) * d.r);
     const int cmin = -max(0, last_off), cmax = span - 1 - min(0, last_off);
-    const int c0 = cmin + (int)blockIdx.x * kStOwn;
+    const int c0 = cmin + (int)blockIdx.x * OWN;
     if (c0 > cmax) return;
     const int start = d.s < 0 ? steps - 1 : 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int prow = tid & 31, pgrp = tid >> 5;  // load/store mapping: 8 groups x 32 rows per pass
     const int ntiles = (steps + TS - 1) / TS;
+    // groups of a tile that this slice can touch: chains + the drift over TS - 1 steps (|round(a) - round(b)| <=
+    // ceil(|a - b|) + 1) + up to 3 columns in front of the first chain (tiles start on a group)
+    const int ng = min(NG, (XC + (int)ceilf((float)(TS - 1) * fabsf(d.r)) + 1 + 3 + 3) >> 2);
     // Units outside the image get an out-of-range offset: loads return 0, stores are dropped, and no memory
     // operation sits behind a branch, so the compiler counts them exactly and the loads of two tiles stay in
     // flight behind the stores of the previous ones.
@@ -1429,7 +1437,7 @@ __device__ __forceinline__ void integral_steep(const float* __restrict__ src, fl
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) {
             const int g = p * 8 + pgrp;
-            regs[p] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, g < NG ? unit_off(xg0 + g, i) : OOB, 0, 0);
+            regs[p] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, g < ng ? unit_off(xg0 + g, i) : OOB, 0, 0);
         }
     };
     float acc = 0.f;
@@ -1447,10 +1455,11 @@ __device__ __forceinline__ void integral_steep(const float* __restrict__ src, fl
         }
         __syncthreads();
         load_tile(t + 2, regs);  // past the last tile every load is out of range
-        if (wave == 0) {
-            // Lane = chain c0 + lane.  At step ii the chain sits in tile column lane + off_ii - (xb - c0): always
+        if (wave < XC / 64) {
+            // Chain c0 + ch, ch = 64 wave + lane.  At step ii it sits in tile column ch + off_ii - (xb - c0): always
             // inside the tile.  No validity test is needed here: elements outside the image or past the last
             // step were loaded as +0 (acc + 0 == acc exactly) and every tile element belongs to exactly one chain.
+            const int ch = wave * 64 + lane;
             const int my_d = off_at(min(i0 + (lane & 31), steps - 1)) - (xb - c0);  // lane j < 32: step i0 + j
             // all 32 reads are issued before the dependent chain of adds (they never alias: one element per
             // step), so the chain costs 32 adds, not 32 LDS round trips
@@ -1458,7 +1467,7 @@ __device__ __forceinline__ void integral_steep(const float* __restrict__ src, fl
             float* cell[TS];
 #pragma unroll
             for (int ii = 0; ii < TS; ++ii) {
-                cell[ii] = &tile[buf][lane + __builtin_amdgcn_readlane(my_d, ii)][ii];
+                cell[ii] = &tile[buf][ch + __builtin_amdgcn_readlane(my_d, ii)][ii];
                 v[ii] = *cell[ii];
             }
 #pragma unroll
@@ -1479,7 +1488,7 @@ __device__ __forceinline__ void integral_steep(const float* __restrict__ src, fl
                 const int gg = g < NG ? g : 0;
                 out.x = __float_as_uint(tile[buf][4 * gg + 0][prow]); out.y = __float_as_uint(tile[buf][4 * gg + 1][prow]);
                 out.z = __float_as_uint(tile[buf][4 * gg + 2][prow]); out.w = __float_as_uint(tile[buf][4 * gg + 3][prow]);
-                const bool mine = g < NG && fc >= c0 && fc < c0 + kStOwn;
+                const bool mine = g < ng && fc >= c0 && fc < c0 + OWN;
                 __builtin_amdgcn_raw_buffer_store_b128(out, rs_out, mine ? unit_off((xb >> 2) + g, i) : OOB, 0, 0);
             }
         }
@@ -1492,6 +1501,8 @@ __device__ __forceinline__ void integral_steep(const float* __restrict__ src, fl
         if (t + 1 < ntiles) process(t + 1, rb);
     }
 }
+template <int XC>
+constexpr size_t integral_lds_bytes() { return (size_t)2 * (XC + 32 + 4) * 33 * sizeof(float); }
 
 // One launch for all slices: blockIdx.y = slice, and the slice's mode picks the sweep.  Shallow and
 // steep slices are independent, so their (latency-bound) blocks overlap instead of running as two
@@ -1500,14 +1511,16 @@ __device__ __forceinline__ void integral_steep(const float* __restrict__ src, fl
 // four such waves on one CU (105 of 256 CUs busy at config 2) ran at 0.061 ms where one per workgroup, spread over
 // all CUs, runs at 0.051.  Large launches (config 5: 25 000 workgroups) fill every CU anyway and put 4 x 58 chains on a
 // workgroup (5.9 against 6.4 ms).
+template <int XC>
 __global__ void __launch_bounds__(256) k_integral(const float* __restrict__ src, float* __restrict__ dst, int W, int H,
                                                   const IntegralDesc* __restrict__ desc,
                                                   const int* __restrict__ tab, int only_mode, int shw) {
+    extern __shared__ float lds_tiles[];
     const int k = blockIdx.y;
     const IntegralDesc d = desc[k];
     if (only_mode && d.mode != only_mode) return;  // timing experiment (FDCM_INT_ONLY): one kind of slice only
     if (d.mode == 1) integral_shallow(src, dst, W, H, d, k, tab, shw);
-    else if (d.mode == 2) integral_steep<64>(src, dst, W, H, d, k);
+    else if (d.mode == 2) integral_steep<XC>(src, dst, W, H, d, k, lds_tiles);
     else {  // nothing to integrate (imgproc.h:43): the slice moves as it is
         const size_t sl = ivol_slice_floats(W, H);
         for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < sl; q += (size_t)gridDim.x * 256)
@@ -1599,6 +1612,8 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after) {
         kb.lcount = (int*)(sb + o_lc); kb.partidx = (int*)(sb + o_pi); kb.flags = (int*)(sb + o_fl);
         kb.dbg = env_debug ? (long long*)(sb + o_dbg) : nullptr;
         kb.NR = (long)NRr; kb.eslots = (int)slots; kb.lslots = (int)lslots;
+        static const int env_aw = getenv("FDCM_K2_AW") ? atoi(getenv("FDCM_K2_AW")) : 0;  // measurement: waves sharing the addend pass
+        kb.addend_waves = env_aw;
     }
     // ---- plan upload: one pinned blob, one async copy
     auto align16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
@@ -1821,8 +1836,20 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after) {
         }
         static const int env_int_only = getenv("FDCM_INT_ONLY") ? atoi(getenv("FDCM_INT_ONLY")) : 0;  // timing experiment
         const int shw = (long)m * ((chains + kShOwn - 1) / kShOwn) > 8192 ? 4 : 1;  // working waves per workgroup of a shallow slice
-        hipLaunchKernelGGL(k_integral, dim3((unsigned)((chains + kShOwn - 1) / kShOwn), (unsigned)m), dim3(256), 0, st,
-                           (const float*)fm->ivol.as<float>(), vol, W, H, d_int, d_tab, env_int_only, shw);
+        // steep slices: 252 own chains per block once 60-chain blocks would outnumber what the GPU holds several times over
+        static const int env_int_xc = getenv("FDCM_INT_XC") ? atoi(getenv("FDCM_INT_XC")) : 0;  // measurement: 64 / 256
+        const bool wide = env_int_xc ? env_int_xc == 256 : (long)m * ((chains + 59) / 60) > 16L * device_cus(fm->device);
+        const dim3 igrid((unsigned)((chains + kShOwn - 1) / kShOwn), (unsigned)m);
+        if (wide) {
+            constexpr size_t lds = integral_lds_bytes<256>();
+            static_assert(lds <= 160 * 1024, "tile pair must fit a CU's LDS");
+            FDCM_HIP(hipFuncSetAttribute((const void*)k_integral<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(k_integral<256>, igrid, dim3(256), lds, st, (const float*)fm->ivol.as<float>(), vol, W, H, d_int, d_tab,
+                               env_int_only, shw);
+        } else {
+            hipLaunchKernelGGL(k_integral<64>, igrid, dim3(256), integral_lds_bytes<64>(), st, (const float*)fm->ivol.as<float>(), vol, W, H,
+                               d_int, d_tab, env_int_only, shw);
+        }
     }
     fm->vol_stage = stop_after >= 3 ? 3 : (stop_after == 2 ? 2 : 1);
     FDCM_HIP(hipEventRecord(ev[5], st));

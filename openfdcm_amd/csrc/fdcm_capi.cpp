@@ -63,7 +63,7 @@ static void destroy(fdcm_featuremap* fm) {
     (void)hipSetDevice(fm->device);
     if (fm->stream) (void)hipStreamSynchronize(fm->stream);
     fm->vol.release(); fm->ivol.release(); fm->bitmap.release(); fm->coldesc.release(); fm->offtab.release(); fm->stack.release(); fm->plan.release(); fm->stage.release();
-    fm->s_scene.release(); fm->s_pairs.release(); fm->s_records.release(); fm->s_flags.release(); fm->s_out.release(); fm->s_work.release(); fm->s_tail.release(); fm->s_tail_out.release();
+    fm->s_scene.release(); fm->s_pairs.release(); fm->s_records.release(); fm->s_flags.release(); fm->s_out.release(); fm->s_work.release(); fm->s_tail.release(); fm->s_tail_out.release(); fm->s_eval.release();
     fm->s_counter.release(); fm->s_stage.release(); fm->s_cnt.release();
     if (fm->timing.created)
         for (auto& e : fm->timing.ev) (void)hipEventDestroy(e);
@@ -224,6 +224,49 @@ int fdcm_featuremap_from_slices(const float* keys, int64_t depth, const float* v
     });
     if (rc != FDCM_OK) { destroy(fm); if (out) *out = nullptr; }
     return rc;
+}
+
+// ------------------------------------------------------------------------------------------ feature-map seam
+static void check_offsets(const int64_t* off, int64_t n, const char* what) {
+    require(off != nullptr, what);
+    require(off[0] == 0, "offsets[0] must be 0");
+    for (int64_t i = 0; i < n; ++i) require(off[i] <= off[i + 1], "offsets must be ascending");
+}
+
+int fdcm_featuremap_minmax_translation_batch(const fdcm_featuremap* fm, const float* tmpl_lines, const int64_t* line_offsets,
+                                             int64_t n_templates, const float* align_vecs, float* out_minmax) {
+    return guarded([&] {
+        require(fm != nullptr, "featuremap is null");
+        require(n_templates >= 0, "negative template count");
+        if (n_templates == 0) return;
+        check_offsets(line_offsets, n_templates, "line_offsets is null");
+        require(line_offsets[n_templates] == 0 || tmpl_lines, "tmpl_lines is null");
+        require(align_vecs && out_minmax, "null align_vecs/out_minmax");
+        run_minmax(const_cast<fdcm_featuremap*>(fm), tmpl_lines, line_offsets, n_templates, align_vecs, out_minmax);
+    });
+}
+
+int fdcm_featuremap_minmax_translation(const fdcm_featuremap* fm, const float* tmpl_lines, int64_t n_lines,
+                                       const float align_vec[2], float out_minmax[2]) {
+    const int64_t off[2] = {0, n_lines};
+    if (n_lines < 0) { set_error("negative line count"); return FDCM_EINVAL; }
+    return fdcm_featuremap_minmax_translation_batch(fm, tmpl_lines, off, 1, align_vec, out_minmax);
+}
+
+int fdcm_featuremap_evaluate(const fdcm_featuremap* fm, const float* tmpl_lines, const int64_t* line_offsets,
+                             int64_t n_templates, const float* translations, const int64_t* translation_offsets,
+                             float* scores_out) {
+    return guarded([&] {
+        require(fm != nullptr, "featuremap is null");
+        require(n_templates >= 0, "negative template count");
+        if (n_templates == 0) return;
+        check_offsets(line_offsets, n_templates, "line_offsets is null");
+        check_offsets(translation_offsets, n_templates, "translation_offsets is null");
+        require(line_offsets[n_templates] == 0 || tmpl_lines, "tmpl_lines is null");
+        require(translation_offsets[n_templates] == 0 || (translations && scores_out), "null translations/scores_out");
+        run_evaluate(const_cast<fdcm_featuremap*>(fm), tmpl_lines, line_offsets, n_templates, translations, translation_offsets,
+                     scores_out);
+    });
 }
 
 // ------------------------------------------------------------------------------------------ templates

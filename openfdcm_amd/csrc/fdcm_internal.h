@@ -145,6 +145,7 @@ struct fdcm_featuremap {
     fdcm::DevBuf s_work;    // search work list: valid pairs grouped by scene line
     fdcm::DevBuf s_tail;    // device tail (penalise + sort + top k) workspace
     fdcm::DevBuf s_tail_out; // the k best of the device tail before their download
+    fdcm::DevBuf s_eval;    // fdcm_featuremap_evaluate / _minmax_translation: lines, translations, work items, results
     int64_t last_n_out = 0; // matches of the last host-output search, still in s_out
     fdcm::DevBuf s_counter;
     fdcm::PinnedBuf s_stage;
@@ -175,6 +176,10 @@ int64_t search_capacity(const fdcm_templates* t, int64_t n_scene, int64_t maxT, 
 void run_search(fdcm_featuremap* fm, const fdcm_templates* t, const float* scene, int64_t n_scene, int64_t maxT,
                 int64_t maxS, int optimizer, int64_t batch, int32_t base, fdcm_match* out_device, fdcm_match** out_host,
                 int64_t* n_out);
+// implemented in fdcm_seam.hip: minmaxTranslation<Dt3Cpu> / evaluate<Dt3Cpu> batched over templates
+void run_minmax(fdcm_featuremap* fm, const float* lines, const int64_t* offsets, int64_t T, const float* align, float* out);
+void run_evaluate(fdcm_featuremap* fm, const float* lines, const int64_t* offsets, int64_t T, const float* translations,
+                  const int64_t* tr_offsets, float* scores);
 // implemented in fdcm_tail.hip
 void run_topk(fdcm_featuremap* fm, const fdcm_templates* t, const fdcm_match* matches_device, int64_t n, int32_t base,
               int penalty, float tau, int64_t k, fdcm_match** out, int64_t* n_out);

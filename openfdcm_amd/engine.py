@@ -94,6 +94,43 @@ class DeviceFeatureMap:
         capi.check(capi.lib().fdcm_featuremap_device_volume_stride(self._h, C.byref(n)))
         return n.value
 
+    def minmax_translation(self, tmpl, align_vec):
+        """FeatureMap::minmaxTranslation (featuremap.h:113-115 -> dt3cpu.cpp:30-75,119-124): (negative, positive)
+        multiplier limits of align_vec for the (4, N) template; runs on the device."""
+        rec = capi.as_records(tmpl)
+        av = np.ascontiguousarray(align_vec, dtype=np.float32).reshape(2)
+        out = np.zeros(2, dtype=np.float32)
+        capi.check(capi.lib().fdcm_featuremap_minmax_translation(self._h, capi.fptr(rec), rec.shape[0], capi.fptr(av),
+                                                                 capi.fptr(out)))
+        return out
+
+    def minmax_translation_batch(self, templates, align_vecs):
+        """One launch for a list of templates with one align vector each -> (T, 2) float32."""
+        flat, offsets = capi.pack_templates(templates)
+        av = np.ascontiguousarray(align_vecs, dtype=np.float32).reshape(len(offsets) - 1, 2)
+        out = np.zeros((len(offsets) - 1, 2), dtype=np.float32)
+        capi.check(capi.lib().fdcm_featuremap_minmax_translation_batch(
+            self._h, capi.fptr(flat), offsets.ctypes.data_as(C.POINTER(C.c_int64)), len(offsets) - 1, capi.fptr(av),
+            capi.fptr(out)))
+        return out
+
+    def evaluate(self, templates, translations):
+        """FeatureMap::evaluate (featuremap.h:117-120 -> dt3cpu.cpp:126-179): templates = list of (4, N) arrays,
+        translations = per template a list / (n, 2) array of (x, y); returns a list of float32 arrays.  One launch."""
+        flat, offsets = capi.pack_templates(templates)
+        if len(translations) != len(offsets) - 1:
+            raise ValueError("one list of translations per template is required")
+        trs = [np.ascontiguousarray(t, dtype=np.float32).reshape(-1, 2) for t in translations]
+        toff = np.zeros(len(trs) + 1, dtype=np.int64)
+        for i, t in enumerate(trs):
+            toff[i + 1] = toff[i] + t.shape[0]
+        tflat = np.ascontiguousarray(np.concatenate(trs, axis=0)) if trs and toff[-1] else np.zeros((0, 2), dtype=np.float32)
+        scores = np.zeros(int(toff[-1]), dtype=np.float32)
+        capi.check(capi.lib().fdcm_featuremap_evaluate(
+            self._h, capi.fptr(flat), offsets.ctypes.data_as(C.POINTER(C.c_int64)), len(offsets) - 1, capi.fptr(tflat),
+            toff.ctypes.data_as(C.POINTER(C.c_int64)), capi.fptr(scores)))
+        return [scores[toff[i]:toff[i + 1]].copy() for i in range(len(trs))]
+
     def build_timing(self):
         t = capi.BuildTiming()
         capi.check(capi.lib().fdcm_featuremap_last_timing(self._h, C.byref(t)))
