@@ -84,6 +84,7 @@ const char* fdcm_version(void);
 
 int fdcm_device_count(int* count);
 int fdcm_set_device(int device); /* device used by handles created afterwards on this thread */
+int fdcm_get_device(int* device); /* the device fdcm_set_device selected on this thread (0 by default) */
 
 /* ---- DT3 feature map: buildCpuFeaturemap<D>, dt3cpu.h:174-234; Python build_cpu_featuremap,
  *      modules/python/src/matching.cpp:116-130 ---- */
@@ -177,13 +178,14 @@ int fdcm_blocks_to_host(const void* blocks_device, int32_t n_blocks, int64_t cap
 /* ---- template shards over several GPUs of one node, from ONE process (the reference's own
  *      parallel seam is the per-candidate task loop, batchoptimize.cpp:102-114) ----
  * The template list is cut into contiguous index ranges, one per device; every device rebuilds the DT3 volume itself
- * from the scene lines (one host thread per device runs rebuild -> search) and the match records -- in top-k mode the
+ * from the scene lines (a long-lived host thread per device runs rebuild -> search) and the match records -- in top-k mode the
  * k best of every shard (penalise + stable sort on each device) -- travel to the first device in ONE grouped RCCL
  * send/recv per frame with exact sizes; no count exchange is needed because all shards live in this process.
  * fdcm_sharded_search returns what fdcm_search returns for the whole list on one device (same records, same order);
  * fdcm_sharded_search_topk returns what fdcm_topk returns for it.  devices = NULL means devices 0..n_devices-1.
  * RCCL (librccl.so.1) is bound at run time, only when n_devices > 1 or FDCM_SHARDED_ALWAYS_COLLECTIVE is set (then a
- * single shard also sends its records to itself through RCCL: a test hook for one-GPU machines). */
+ * single shard also sends its records to itself through RCCL: a test hook for one-GPU machines).  Every entry point
+ * leaves the caller's current device (the library's and HIP's) as it found it. */
 #define FDCM_SHARDED_ALWAYS_COLLECTIVE 1
 typedef struct fdcm_sharded fdcm_sharded;
 int fdcm_sharded_create(const int* devices, int n_devices, const float* tmpl_lines, const int64_t* offsets /* n_templates+1 */,
@@ -195,6 +197,20 @@ int fdcm_sharded_search(fdcm_sharded* s, const float* scene_lines, int64_t n_sce
 int fdcm_sharded_search_topk(fdcm_sharded* s, const float* scene_lines, int64_t n_scene_lines, int64_t max_tmpl_lines,
                              int64_t max_scene_lines, int optimizer, int64_t batch_size, int penalty, float tau, int64_t k,
                              fdcm_match** out, int64_t* n_out);
+/* Frames in flight (like fdcm_pipeline_* on one device): the engine keeps n_frames frame slots per device, each with its
+ * own feature map and a long-lived host thread.  fdcm_sharded_submit copies the scene lines, hands the frame to the
+ * workers of every device and returns a ticket (tickets count up from 0; ticket t uses slot t % n_frames, so at most
+ * n_frames tickets may be outstanding); fdcm_sharded_wait blocks until the frame is complete on every device, runs its
+ * exchange and returns exactly what the blocking call returns -- while the workers compute the frames submitted
+ * after it.  fdcm_sharded_search / _search_topk are submit + wait.  One caller thread at a time per engine; n_frames
+ * is 1 after create and may be changed (1..16) while no frame is in flight. */
+int fdcm_sharded_set_frames_in_flight(fdcm_sharded* s, int n_frames);
+int fdcm_sharded_submit(fdcm_sharded* s, const float* scene_lines, int64_t n_scene_lines, int64_t max_tmpl_lines,
+                        int64_t max_scene_lines, int optimizer, int64_t batch_size, int64_t* ticket);
+int fdcm_sharded_submit_topk(fdcm_sharded* s, const float* scene_lines, int64_t n_scene_lines, int64_t max_tmpl_lines,
+                             int64_t max_scene_lines, int optimizer, int64_t batch_size, int penalty, float tau, int64_t k,
+                             int64_t* ticket);
+int fdcm_sharded_wait(fdcm_sharded* s, int64_t ticket, fdcm_match** out, int64_t* n_out);
 /* devices / shard_begin (n_devices + 1 entries: shard i holds templates [shard_begin[i], shard_begin[i+1])) may be NULL;
  * collectives = grouped send/recv operations issued so far, bytes_moved = bytes they carried. */
 int fdcm_sharded_info(const fdcm_sharded* s, int* n_devices, int* devices, int64_t* shard_begin, int64_t* collectives,

@@ -43,6 +43,7 @@ SYMBOLS = [
     ("fdcm_version", C.c_char_p, []),
     ("fdcm_device_count", C.c_int, [C.POINTER(C.c_int)]),
     ("fdcm_set_device", C.c_int, [C.c_int]),
+    ("fdcm_get_device", C.c_int, [C.POINTER(C.c_int)]),
     ("fdcm_featuremap_build", C.c_int, [_fp, C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_int, C.POINTER(_vp)]),
     ("fdcm_featuremap_rebuild", C.c_int, [_vp, _fp, C.c_int64]),
     ("fdcm_featuremap_free", C.c_int, [_vp]),
@@ -83,6 +84,11 @@ SYMBOLS = [
     ("fdcm_sharded_search", C.c_int, [_vp, _fp, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int64, C.POINTER(_vp), _i64p]),
     ("fdcm_sharded_search_topk", C.c_int, [_vp, _fp, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_float,
                                            C.c_int64, C.POINTER(_vp), _i64p]),
+    ("fdcm_sharded_set_frames_in_flight", C.c_int, [_vp, C.c_int]),
+    ("fdcm_sharded_submit", C.c_int, [_vp, _fp, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int64, _i64p]),
+    ("fdcm_sharded_submit_topk", C.c_int, [_vp, _fp, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_float,
+                                           C.c_int64, _i64p]),
+    ("fdcm_sharded_wait", C.c_int, [_vp, C.c_int64, C.POINTER(_vp), _i64p]),
     ("fdcm_sharded_info", C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), _i64p, _i64p, _i64p]),
     ("fdcm_sharded_last_timing", C.c_int, [_vp, C.c_int, C.POINTER(BuildTiming), C.POINTER(SearchTiming)]),
     ("fdcm_sharded_free", C.c_int, [_vp]),

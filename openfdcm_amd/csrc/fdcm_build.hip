@@ -1584,12 +1584,15 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after) {
     if (fm->distance != FDCM_L1) {
         // scratch of the L2 sweeps: envelope entries (W + kSegMax + 2 slots per row, 12 B), owner list (W + 2
         // entries per row, 8 B), per-segment and per-row records, chunk flags
-        const size_t NRr = (size_t)nchunks * 64, slots = (size_t)W + kSegMax + 2, lslots = (size_t)W + 2;
+        // (the one-wave-per-chunk kernel alone -- volumes above 2^32 pixels -- only needs its (v, f, z) spill space,
+        // 12 B per pixel, which is the entry area: no owner list and no per-segment records then)
+        const size_t NRr = (size_t)nchunks * 64, slots = segmented ? (size_t)W + kSegMax + 2 : (size_t)W, lslots = (size_t)W + 2;
         size_t off = 0;
         auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
-        const size_t o_ent = take(slots * NRr * sizeof(EnvEntry)), o_own = take(lslots * NRr * sizeof(OwnEntry));
-        const size_t o_tc = take(kSegMax * NRr * 4), o_tm = take(kSegMax * NRr * 4), o_ts = take(kSegMax * NRr * 4);
-        const size_t o_lc = take(NRr * 4), o_pi = take(3 * NRr * 4), o_fl = take((size_t)nchunks * 4);
+        const size_t segw = segmented ? 1 : 0;
+        const size_t o_ent = take(slots * NRr * sizeof(EnvEntry)), o_own = take(segw * lslots * NRr * sizeof(OwnEntry));
+        const size_t o_tc = take(segw * kSegMax * NRr * 4), o_tm = take(segw * kSegMax * NRr * 4), o_ts = take(segw * kSegMax * NRr * 4);
+        const size_t o_lc = take(segw * NRr * 4), o_pi = take(segw * 3 * NRr * 4), o_fl = take((size_t)nchunks * 4);
         const size_t o_dbg = take(env_debug ? (size_t)nchunks * kSegMax * 16 * 8 : 0);
         const size_t o_ord = take((size_t)nchunks * 4), o_cost = take((size_t)nchunks * 4);
         const void* stack_before = fm->stack.p;
@@ -1836,20 +1839,23 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after) {
         }
         static const int env_int_only = getenv("FDCM_INT_ONLY") ? atoi(getenv("FDCM_INT_ONLY")) : 0;  // timing experiment
         const int shw = (long)m * ((chains + kShOwn - 1) / kShOwn) > 8192 ? 4 : 1;  // working waves per workgroup of a shallow slice
-        // steep slices: 252 own chains per block once 60-chain blocks would outnumber what the GPU holds several times over
-        static const int env_int_xc = getenv("FDCM_INT_XC") ? atoi(getenv("FDCM_INT_XC")) : 0;  // measurement: 64 / 256
-        const bool wide = env_int_xc ? env_int_xc == 256 : (long)m * ((chains + 59) / 60) > 16L * device_cus(fm->device);
+        // steep slices: 60 own chains per block while the launch is small, 124 / 252 once such blocks would outnumber
+        // what the GPU holds several times over (fewer columns read twice; see integral_steep)
+        static const int env_int_xc = getenv("FDCM_INT_XC") ? atoi(getenv("FDCM_INT_XC")) : 0;  // measurement: 64 / 128 / 256
+        const long narrow_blocks = (long)m * ((chains + 59) / 60), cus = device_cus(fm->device);
+        const int xc = env_int_xc ? env_int_xc : (narrow_blocks > 64 * cus ? 256 : (narrow_blocks > 12 * cus ? 128 : 64));
         const dim3 igrid((unsigned)((chains + kShOwn - 1) / kShOwn), (unsigned)m);
-        if (wide) {
-            constexpr size_t lds = integral_lds_bytes<256>();
-            static_assert(lds <= 160 * 1024, "tile pair must fit a CU's LDS");
-            FDCM_HIP(hipFuncSetAttribute((const void*)k_integral<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(k_integral<256>, igrid, dim3(256), lds, st, (const float*)fm->ivol.as<float>(), vol, W, H, d_int, d_tab,
-                               env_int_only, shw);
-        } else {
-            hipLaunchKernelGGL(k_integral<64>, igrid, dim3(256), integral_lds_bytes<64>(), st, (const float*)fm->ivol.as<float>(), vol, W, H,
-                               d_int, d_tab, env_int_only, shw);
-        }
+#define FDCM_INTEGRAL(XC)                                                                                                        \
+        do {                                                                                                                     \
+            constexpr size_t lds = integral_lds_bytes<XC>();                                                                     \
+            static_assert(lds <= 160 * 1024, "tile pair must fit a CU's LDS");                                                   \
+            if (lds > 64 * 1024)                                                                                                 \
+                FDCM_HIP(hipFuncSetAttribute((const void*)k_integral<XC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            hipLaunchKernelGGL(k_integral<XC>, igrid, dim3(256), lds, st, (const float*)fm->ivol.as<float>(), vol, W, H, d_int,  \
+                               d_tab, env_int_only, shw);                                                                        \
+        } while (0)
+        if (xc == 256) FDCM_INTEGRAL(256); else if (xc == 128) FDCM_INTEGRAL(128); else FDCM_INTEGRAL(64);
+#undef FDCM_INTEGRAL
     }
     fm->vol_stage = stop_after >= 3 ? 3 : (stop_after == 2 ? 2 : 1);
     FDCM_HIP(hipEventRecord(ev[5], st));

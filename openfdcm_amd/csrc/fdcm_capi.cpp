@@ -93,6 +93,13 @@ int fdcm_set_device(int device) {
     });
 }
 
+int fdcm_get_device(int* device) {
+    return guarded([&] {
+        require(device != nullptr, "device is null");
+        *device = g_device;
+    });
+}
+
 int fdcm_featuremap_build_staged(const float* scene_lines, int64_t n_lines, int64_t depth, float dt3_coeff,
                                  float padding, int distance, int stop_after, fdcm_featuremap** out) {
     fdcm_featuremap* fm = nullptr;
@@ -455,9 +462,22 @@ int fdcm_blocks_to_host(const void* blocks_device, int32_t n_blocks, int64_t cap
     int rc = guarded([&] {
         require(out && n_out && n_blocks >= 0 && capacity_records >= 0 && (n_blocks == 0 || blocks_device), "bad arguments");
         require((int64_t)n_blocks * capacity_records < (int64_t)1 << 40, "too many records");
-        FDCM_HIP(hipSetDevice(g_device));
         if (n_blocks == 0 || capacity_records == 0) { *out = result_acquire(64); return; }
-        blocks_to_host((hipStream_t)stream, blocks_device, n_blocks, capacity_records, out, n_out);
+        // the kernel runs on the device that holds the blocks (whatever this thread's current device is), and the
+        // caller's current device is left as it was
+        int prev = -1;
+        (void)hipGetDevice(&prev);
+        hipPointerAttribute_t attr{};
+        const int dev = hipPointerGetAttributes(&attr, blocks_device) == hipSuccess ? attr.device : g_device;
+        (void)hipGetLastError();
+        FDCM_HIP(hipSetDevice(dev));
+        try {
+            blocks_to_host((hipStream_t)stream, blocks_device, n_blocks, capacity_records, out, n_out);
+        } catch (...) {
+            if (prev >= 0) (void)hipSetDevice(prev);
+            throw;
+        }
+        if (prev >= 0) (void)hipSetDevice(prev);
     });
     if (rc != FDCM_OK && out && *out) { result_release(*out); *out = nullptr; }
     return rc;

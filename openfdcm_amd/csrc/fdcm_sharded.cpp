@@ -4,9 +4,10 @@
 // list is split into contiguous index ranges, one per device; every device rebuilds the volume itself from the scene
 // lines (16 B per line; cheaper than moving V over a 153 GB/s xGMI link) and searches its range.  The reference's own
 // parallel seam is the per-candidate task loop of optimize<BatchOptimize> (batchoptimize.cpp:102-114); here the seam
-// is the template index.  One host thread per device runs rebuild -> search (the blocking entry points of fdcm.h),
-// then the match records -- or, in top-k mode, the k best of every shard -- travel to the first device in ONE grouped
-// RCCL send/recv.  The counts need no exchange: all shards live in this process, so every transfer has its exact size
+// is the template index.  Long-lived host threads, one per device and frame slot, run rebuild -> search (the blocking
+// entry points of fdcm.h); fdcm_sharded_submit hands a frame to the slot workers of every device and returns,
+// fdcm_sharded_wait collects it: the match records -- or, in top-k mode, the k best of every shard -- travel to the
+// first device in ONE grouped RCCL send/recv, issued by the caller's thread while the workers compute later frames.  The counts need no exchange: all shards live in this process, so every transfer has its exact size
 // and lands at its final offset; concatenation in shard order is the reference's positional order because the ranges
 // are contiguous (defaultmatch.cpp:51-86).
 //
@@ -15,7 +16,9 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <condition_variable>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -68,14 +71,27 @@ void nccl_check(ncclResult_t rc, const char* what) {
     if (rc != 0) throw std::string("RCCL error in ") + what + ": " + (rccl().GetErrorString ? rccl().GetErrorString(rc) : "?");
 }
 
-struct Shard {
-    int device = 0;
-    int64_t begin = 0, end = 0;        // template range
-    fdcm_templates* tset = nullptr;
+// One frame slot of a shard: its own feature map (volume, workspaces, stream), result buffers and a long-lived host
+// thread that runs  rebuild -> search (-> device tail)  for the frames it is handed.  Ticket t of the engine runs on
+// slot t % n_slots of EVERY shard, so the slots of one index form a frame; frames on different slots overlap on the
+// devices, and the exchange of frame i (caller's thread, in fdcm_sharded_wait) runs while the workers compute i + 1...
+struct Job {
+    std::vector<float> scene;
+    int64_t n_scene = 0, maxT = 0, maxS = 0, batch = 1, k = 0;
+    int optimizer = 0, penalty = -1;
+    float tau = 1.f;
+    bool topk = false;
+};
+
+struct FrameSlot {
+    std::thread worker;
+    std::mutex mu;
+    std::condition_variable cv;
+    bool has_job = false, done = true, quit = false;
+    Job job;
     fdcm_featuremap* fm = nullptr;
-    fdcm::DevBuf block;                // this shard's match records (search capacity of the frame)
-    fdcm::DevBuf best;                 // top-k mode: the shard's k best
-    hipStream_t stream = nullptr;      // the collective's stream on this device
+    fdcm::DevBuf block;                // this slot's match records (search capacity of the frame)
+    fdcm::DevBuf best;                 // top-k mode: the k best
     // per-frame results of the worker
     int rc = FDCM_OK;
     std::string error;
@@ -83,6 +99,31 @@ struct Shard {
     const fdcm_match* send_from = nullptr;
     fdcm_build_timing bt{};
     fdcm_search_timing st{};
+};
+
+struct Shard {
+    int device = 0;
+    int64_t begin = 0, end = 0;        // template range
+    fdcm_templates* tset = nullptr;
+    hipStream_t stream = nullptr;      // the collective's stream on this device
+    std::vector<std::unique_ptr<FrameSlot>> slots;
+    fdcm_build_timing bt{};            // of the frame collected last
+    fdcm_search_timing st{};
+};
+
+// The caller's device (the library's thread-local one and HIP's) is restored when an entry point returns: the engine
+// switches devices on the caller's thread for allocations, streams and the exchange.
+struct DeviceGuard {
+    int lib_dev = 0, hip_dev = 0;
+    bool have_hip = false;
+    DeviceGuard() {
+        (void)fdcm_get_device(&lib_dev);
+        have_hip = hipGetDevice(&hip_dev) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        (void)fdcm_set_device(lib_dev);  // sets HIP's current device too
+        if (have_hip) (void)hipSetDevice(hip_dev);
+    }
 };
 
 }  // namespace
@@ -94,6 +135,10 @@ struct fdcm_sharded {
     int64_t depth = 0;
     float coeff = 0.f, padding = 0.f;
     int distance = 0;
+    int n_slots = 0;
+    int64_t next_ticket = 0;
+    std::vector<int64_t> slot_ticket;   // ticket held by every slot index (-1 = free)
+    std::vector<Job> slot_job;          // what that ticket asked for (the tail of a top-k frame needs k)
     fdcm::DevBuf gathered;   // on the first device: all shards' records back to back
     int64_t collectives = 0; // grouped send/recv operations issued so far
     int64_t bytes_moved = 0; // bytes that crossed between devices (or through RCCL) so far
@@ -127,68 +172,140 @@ int guarded_s(F&& f) {
     }
 }
 
-// rebuild -> search on every shard, one host thread per device; top-k mode adds the device tail per shard
-void run_shards(fdcm_sharded* s, const float* scene, int64_t n_scene, int64_t maxT, int64_t maxS, int optimizer, int64_t batch,
-                bool topk, int penalty, float tau, int64_t k) {
-    std::vector<std::thread> th;
-    for (size_t i = 0; i < s->shards.size(); ++i) {
-        th.emplace_back([&, i] {
-            Shard& sh = s->shards[i];
-            sh.rc = FDCM_OK; sh.n = 0; sh.send_from = nullptr; sh.error.clear();
-            auto fail = [&](int rc) { sh.rc = rc; sh.error = fdcm_last_error(); };
-            int rc = fdcm_set_device(sh.device);
-            if (rc != FDCM_OK) return fail(rc);
-            rc = sh.fm ? fdcm_featuremap_rebuild(sh.fm, scene, n_scene)
-                       : fdcm_featuremap_build(scene, n_scene, s->depth, s->coeff, s->padding, s->distance, &sh.fm);
-            if (rc != FDCM_OK) return fail(rc);
-            int64_t cap = 0;
-            rc = fdcm_search_capacity(sh.tset, n_scene, maxT, maxS, &cap);
-            if (rc != FDCM_OK) return fail(rc);
-            try {
-                FDCM_HIP(hipSetDevice(sh.device));
-                sh.block.reserve(std::max<size_t>(32, (size_t)cap * sizeof(fdcm_match)));
-            } catch (const HipError& e) {
-                set_error(std::string("HIP error: ") + hipGetErrorString(e.code) + " in " + e.what);
-                return fail(FDCM_EHIP);
-            }
-            int64_t n = 0;
-            rc = fdcm_search_device(sh.fm, sh.tset, scene, n_scene, maxT, maxS, optimizer, batch, (int32_t)sh.begin,
-                                    sh.block.as<fdcm_match>(), &n);
-            if (rc != FDCM_OK) return fail(rc);
-            (void)fdcm_featuremap_last_timing(sh.fm, &sh.bt);
-            (void)fdcm_search_last_timing(sh.fm, &sh.st);
-            sh.n = n;
-            sh.send_from = sh.block.as<fdcm_match>();
-            if (topk) {
-                try {
-                    const int64_t kk = std::min<int64_t>(std::max<int64_t>(k, 0), n);
-                    FDCM_HIP(hipSetDevice(sh.device));
-                    sh.best.reserve(std::max<size_t>(32, (size_t)kk * sizeof(fdcm_match)));
-                    fdcm::run_topk_device(sh.fm, sh.tset, sh.block.as<fdcm_match>(), n, (int32_t)sh.begin, penalty, tau, kk,
-                                          sh.best.as<fdcm_match>());
-                    sh.n = kk;
-                    sh.send_from = sh.best.as<fdcm_match>();
-                } catch (const HipError& e) {
-                    set_error(std::string("HIP error: ") + hipGetErrorString(e.code) + " in " + e.what);
-                    return fail(FDCM_EHIP);
-                } catch (const std::string& e) {
-                    set_error(e);
-                    return fail(FDCM_EINVAL);
-                }
-            }
-        });
-    }
-    for (auto& t : th) t.join();
-    for (auto& sh : s->shards)
-        if (sh.rc != FDCM_OK) throw std::string("shard on device ") + std::to_string(sh.device) + ": " + sh.error;
+// rebuild -> search on one slot of one shard; top-k mode adds the device tail.  Never throws: whatever goes wrong is
+// recorded in the slot (a worker thread has nobody to throw to).
+void run_slot_frame(fdcm_sharded* s, Shard& sh, FrameSlot& fs) {
+    fs.rc = FDCM_OK; fs.n = 0; fs.send_from = nullptr; fs.error.clear();
+    const Job& j = fs.job;
+    const int rc = guarded_s([&] {
+        auto ok = [&](int r) { if (r != FDCM_OK) throw std::string(fdcm_last_error()); };
+        const float* scene = j.scene.data();
+        ok(fs.fm ? fdcm_featuremap_rebuild(fs.fm, scene, j.n_scene)
+                 : fdcm_featuremap_build(scene, j.n_scene, s->depth, s->coeff, s->padding, s->distance, &fs.fm));
+        int64_t cap = 0;
+        ok(fdcm_search_capacity(sh.tset, j.n_scene, j.maxT, j.maxS, &cap));
+        FDCM_HIP(hipSetDevice(sh.device));
+        fs.block.reserve(std::max<size_t>(32, (size_t)cap * sizeof(fdcm_match)));
+        int64_t n = 0;
+        ok(fdcm_search_device(fs.fm, sh.tset, scene, j.n_scene, j.maxT, j.maxS, j.optimizer, j.batch, (int32_t)sh.begin,
+                              fs.block.as<fdcm_match>(), &n));
+        (void)fdcm_featuremap_last_timing(fs.fm, &fs.bt);
+        (void)fdcm_search_last_timing(fs.fm, &fs.st);
+        fs.n = n;
+        fs.send_from = fs.block.as<fdcm_match>();
+        if (j.topk) {
+            const int64_t kk = std::min<int64_t>(std::max<int64_t>(j.k, 0), n);
+            fs.best.reserve(std::max<size_t>(32, (size_t)kk * sizeof(fdcm_match)));
+            fdcm::run_topk_device(fs.fm, sh.tset, fs.block.as<fdcm_match>(), n, (int32_t)sh.begin, j.penalty, j.tau, kk,
+                                  fs.best.as<fdcm_match>());
+            fs.n = kk;
+            fs.send_from = fs.best.as<fdcm_match>();
+        }
+    });
+    if (rc != FDCM_OK) { fs.rc = rc; fs.error = fdcm_last_error(); fs.n = 0; fs.send_from = nullptr; }
 }
 
-// All shards' records to the first device, back to back in shard order: ONE grouped send/recv with exact sizes.
-// Returns the total record count; the records are at s->gathered on device shards[0].device, complete when the
-// first shard's stream has been synchronised (done here).
-int64_t gather_to_first(fdcm_sharded* s) {
+void slot_worker(fdcm_sharded* s, Shard* sh, FrameSlot* fs) {
+    (void)fdcm_set_device(sh->device);
+    std::unique_lock<std::mutex> lk(fs->mu);
+    while (true) {
+        fs->cv.wait(lk, [&] { return fs->has_job || fs->quit; });
+        if (fs->quit) break;
+        fs->has_job = false;
+        lk.unlock();
+        try {
+            run_slot_frame(s, *sh, *fs);
+        } catch (...) {  // (run_slot_frame catches everything itself; a worker must never take the process down)
+            fs->rc = FDCM_EINTERNAL; fs->error = "unknown error in a shard worker"; fs->n = 0;
+        }
+        lk.lock();
+        fs->done = true;
+        fs->cv.notify_all();
+    }
+    lk.unlock();
+    if (fs->fm) (void)fdcm_featuremap_free(fs->fm);
+    fs->fm = nullptr;
+    (void)hipSetDevice(sh->device);
+    fs->block.release();
+    fs->best.release();
+}
+
+void stop_workers(fdcm_sharded* s) {
+    for (auto& sh : s->shards) {
+        for (auto& sp : sh.slots) {
+            FrameSlot& fs = *sp;
+            {
+                std::unique_lock<std::mutex> lk(fs.mu);
+                fs.cv.wait(lk, [&] { return fs.done; });  // a frame in flight finishes first
+                fs.quit = true;
+                fs.cv.notify_all();
+            }
+            if (fs.worker.joinable()) fs.worker.join();
+        }
+        sh.slots.clear();
+    }
+    s->n_slots = 0;
+    s->slot_ticket.clear();
+    s->slot_job.clear();
+}
+
+void start_workers(fdcm_sharded* s, int n_slots) {
+    stop_workers(s);
+    for (auto& sh : s->shards)
+        for (int i = 0; i < n_slots; ++i) {
+            sh.slots.emplace_back(new FrameSlot());
+            FrameSlot* fs = sh.slots.back().get();
+            try {
+                fs->worker = std::thread(slot_worker, s, &sh, fs);
+            } catch (...) {  // thread creation failed: the ones already running are joined by stop_workers
+                sh.slots.pop_back();
+                s->n_slots = n_slots;
+                stop_workers(s);
+                throw std::string("could not start a shard worker thread");
+            }
+        }
+    s->n_slots = n_slots;
+    s->slot_ticket.assign((size_t)n_slots, -1);
+    s->slot_job.assign((size_t)n_slots, Job{});
+}
+
+int64_t submit_frame(fdcm_sharded* s, Job&& job) {
+    if (s->n_slots == 0) start_workers(s, 1);
+    const size_t si = (size_t)(s->next_ticket % s->n_slots);
+    if (s->slot_ticket[si] >= 0) throw std::string("every frame slot holds a frame that has not been waited for");
+    for (auto& sh : s->shards) {
+        FrameSlot& fs = *sh.slots[si];
+        std::unique_lock<std::mutex> lk(fs.mu);
+        fs.job = job;  // (a copy per shard: a few KB of scene lines)
+        fs.done = false;
+        fs.has_job = true;
+        fs.cv.notify_all();
+    }
+    s->slot_job[si] = std::move(job);
+    s->slot_job[si].scene.clear();
+    s->slot_ticket[si] = s->next_ticket;
+    return s->next_ticket++;
+}
+
+// Waits for every shard's worker of the slot; throws the first failure after all of them have finished.
+void wait_slot(fdcm_sharded* s, size_t si) {
+    std::string err;
+    for (auto& sh : s->shards) {
+        FrameSlot& fs = *sh.slots[si];
+        std::unique_lock<std::mutex> lk(fs.mu);
+        fs.cv.wait(lk, [&] { return fs.done; });
+        if (fs.rc != FDCM_OK && err.empty()) err = std::string("shard on device ") + std::to_string(sh.device) + ": " + fs.error;
+        sh.bt = fs.bt; sh.st = fs.st;
+    }
+    if (!err.empty()) throw err;
+}
+
+// All shards' records of one frame slot to the first device, back to back in shard order: ONE grouped send/recv with
+// exact sizes.  Returns the total record count; the records are at s->gathered on device shards[0].device, complete
+// when the first shard's stream has been synchronised (done here).
+int64_t gather_to_first(fdcm_sharded* s, size_t si) {
     std::vector<int64_t> off(s->shards.size() + 1, 0);
-    for (size_t i = 0; i < s->shards.size(); ++i) off[i + 1] = off[i] + s->shards[i].n;
+    for (size_t i = 0; i < s->shards.size(); ++i) off[i + 1] = off[i] + s->shards[i].slots[si]->n;
     const int64_t total = off.back();
     Shard& root = s->shards[0];
     FDCM_HIP(hipSetDevice(root.device));
@@ -196,7 +313,7 @@ int64_t gather_to_first(fdcm_sharded* s) {
     fdcm_match* dst = s->gathered.as<fdcm_match>();
     const bool single = s->shards.size() == 1 && !s->always_collective;
     if (single) {  // nothing to exchange: the records already are on the first (only) device
-        if (total) FDCM_HIP(hipMemcpyAsync(dst, root.send_from, (size_t)total * sizeof(fdcm_match), hipMemcpyDeviceToDevice, root.stream));
+        if (total) FDCM_HIP(hipMemcpyAsync(dst, root.slots[si]->send_from, (size_t)total * sizeof(fdcm_match), hipMemcpyDeviceToDevice, root.stream));
         FDCM_HIP(hipStreamSynchronize(root.stream));
         return total;
     }
@@ -205,16 +322,17 @@ int64_t gather_to_first(fdcm_sharded* s) {
     nccl_check(R.GroupStart(), "ncclGroupStart");
     for (size_t i = 0; i < s->shards.size(); ++i) {
         Shard& sh = s->shards[i];
-        if (sh.n == 0) continue;
-        const size_t bytes = (size_t)sh.n * sizeof(fdcm_match);
-        nccl_check(R.Send(sh.send_from, bytes, kNcclUint8, 0, s->comms[i], sh.stream), "ncclSend");
+        const FrameSlot& fs = *sh.slots[si];
+        if (fs.n == 0) continue;
+        const size_t bytes = (size_t)fs.n * sizeof(fdcm_match);
+        nccl_check(R.Send(fs.send_from, bytes, kNcclUint8, 0, s->comms[i], sh.stream), "ncclSend");
         nccl_check(R.Recv(dst + off[i], bytes, kNcclUint8, (int)i, s->comms[0], root.stream), "ncclRecv");
         s->bytes_moved += (int64_t)bytes;
         any = true;
     }
     nccl_check(R.GroupEnd(), "ncclGroupEnd");
     if (any) ++s->collectives;
-    for (auto& sh : s->shards) {  // the send buffers are reused by the next frame
+    for (auto& sh : s->shards) {  // the slot's send buffers are reused by its next frame
         FDCM_HIP(hipSetDevice(sh.device));
         FDCM_HIP(hipStreamSynchronize(sh.stream));
     }
@@ -237,17 +355,52 @@ fdcm_match* download(fdcm_sharded* s, int64_t total) {
     return out;
 }
 
+void collect_frame(fdcm_sharded* s, int64_t ticket, fdcm_match** out, int64_t* n_out) {
+    *out = nullptr; *n_out = 0;
+    if (ticket < 0 || s->n_slots == 0) throw std::string("unknown ticket");
+    const size_t si = (size_t)(ticket % s->n_slots);
+    if (s->slot_ticket[si] != ticket) throw std::string("unknown or already collected ticket");
+    s->slot_ticket[si] = -1;  // whatever happens below, the slot is free again
+    wait_slot(s, si);
+    const Job& job = s->slot_job[si];
+    const int64_t total = gather_to_first(s, si);  // top-k mode: at most k records per shard cross the links
+    fdcm_match* all = download(s, total);
+    if (job.topk) {
+        // every shard's list is ascending by score with ties in positional order, and the lists arrive in shard order:
+        // a stable sort by score keeps ties in (shard, position) = global positional order
+        std::stable_sort(all, all + total, [](const fdcm_match& a, const fdcm_match& b) {
+            return fdcm::ordered_key_host(a.score) < fdcm::ordered_key_host(b.score);
+        });
+        *n_out = std::min<int64_t>(job.k, total);
+    } else {
+        *n_out = total;
+    }
+    *out = all;
+}
+
+Job make_job(const float* scene, int64_t n_scene, int64_t maxT, int64_t maxS, int optimizer, int64_t batch, bool topk, int penalty,
+             float tau, int64_t k) {
+    if (n_scene < 0 || (n_scene > 0 && !scene)) throw std::string("bad scene_lines");
+    if (maxT < 0 || maxS < 0) throw std::string("negative search window");
+    if (optimizer < FDCM_DEFAULT_OPTIMIZE || optimizer > FDCM_INDULGENT_OPTIMIZE) throw std::string("unknown optimizer");
+    if (topk && (penalty < -1 || penalty > FDCM_EXPONENTIAL_PENALTY)) throw std::string("unknown penalty");
+    if (topk && k < 0) throw std::string("k must be >= 0");
+    Job j;
+    j.scene.assign(scene, scene + 4 * n_scene);
+    j.n_scene = n_scene; j.maxT = maxT; j.maxS = maxS; j.optimizer = optimizer; j.batch = batch;
+    j.topk = topk; j.penalty = penalty; j.tau = tau; j.k = k;
+    return j;
+}
+
 void destroy_sharded(fdcm_sharded* s) {
     if (!s) return;
+    stop_workers(s);
     for (size_t i = 0; i < s->comms.size(); ++i)
         if (s->comms[i] && rccl().CommDestroy) (void)rccl().CommDestroy(s->comms[i]);
     for (auto& sh : s->shards) {
         (void)hipSetDevice(sh.device);
         if (sh.stream) { (void)hipStreamSynchronize(sh.stream); (void)hipStreamDestroy(sh.stream); }
-        if (sh.fm) (void)fdcm_featuremap_free(sh.fm);
         if (sh.tset) (void)fdcm_templates_free(sh.tset);
-        sh.block.release();
-        sh.best.release();
     }
     if (!s->shards.empty()) (void)hipSetDevice(s->shards[0].device);
     s->gathered.release();
@@ -261,6 +414,7 @@ extern "C" {
 int fdcm_sharded_create(const int* devices, int n_devices, const float* tmpl_lines, const int64_t* offsets, int64_t n_templates,
                         int64_t depth, float dt3_coeff, float padding, int distance, int flags, fdcm_sharded** out) {
     fdcm_sharded* s = nullptr;
+    DeviceGuard guard;
     int rc = guarded_s([&] {
         if (!out) throw std::string("out is null");
         *out = nullptr;
@@ -300,6 +454,7 @@ int fdcm_sharded_create(const int* devices, int n_devices, const float* tmpl_lin
             s->comms.assign((size_t)n_devices, nullptr);
             nccl_check(R.CommInitAll(s->comms.data(), n_devices, devs.data()), "ncclCommInitAll");
         }
+        start_workers(s, 1);
         *out = s;
     });
     if (rc != FDCM_OK) destroy_sharded(s);
@@ -307,7 +462,19 @@ int fdcm_sharded_create(const int* devices, int n_devices, const float* tmpl_lin
 }
 
 int fdcm_sharded_free(fdcm_sharded* s) {
+    DeviceGuard guard;
     return guarded_s([&] { destroy_sharded(s); });
+}
+
+int fdcm_sharded_set_frames_in_flight(fdcm_sharded* s, int n_frames) {
+    DeviceGuard guard;
+    return guarded_s([&] {
+        if (!s) throw std::string("null handle");
+        if (n_frames < 1 || n_frames > 16) throw std::string("n_frames must be 1..16");
+        for (int64_t t : s->slot_ticket)
+            if (t >= 0) throw std::string("frames are in flight: collect them with fdcm_sharded_wait first");
+        if (n_frames != s->n_slots) start_workers(s, n_frames);
+    });
 }
 
 int fdcm_sharded_info(const fdcm_sharded* s, int* n_devices, int* devices, int64_t* shard_begin, int64_t* collectives,
@@ -326,36 +493,55 @@ int fdcm_sharded_info(const fdcm_sharded* s, int* n_devices, int* devices, int64
     });
 }
 
+int fdcm_sharded_submit(fdcm_sharded* s, const float* scene_lines, int64_t n_scene_lines, int64_t max_tmpl_lines,
+                        int64_t max_scene_lines, int optimizer, int64_t batch_size, int64_t* ticket) {
+    return guarded_s([&] {
+        if (!s || !ticket) throw std::string("null argument");
+        *ticket = submit_frame(s, make_job(scene_lines, n_scene_lines, max_tmpl_lines, max_scene_lines, optimizer, batch_size, false,
+                                           -1, 1.f, 0));
+    });
+}
+
+int fdcm_sharded_submit_topk(fdcm_sharded* s, const float* scene_lines, int64_t n_scene_lines, int64_t max_tmpl_lines,
+                             int64_t max_scene_lines, int optimizer, int64_t batch_size, int penalty, float tau, int64_t k,
+                             int64_t* ticket) {
+    return guarded_s([&] {
+        if (!s || !ticket) throw std::string("null argument");
+        *ticket = submit_frame(s, make_job(scene_lines, n_scene_lines, max_tmpl_lines, max_scene_lines, optimizer, batch_size, true,
+                                           penalty, tau, k));
+    });
+}
+
+int fdcm_sharded_wait(fdcm_sharded* s, int64_t ticket, fdcm_match** out, int64_t* n_out) {
+    DeviceGuard guard;
+    return guarded_s([&] {
+        if (!s || !out || !n_out) throw std::string("null argument");
+        collect_frame(s, ticket, out, n_out);
+    });
+}
+
 int fdcm_sharded_search(fdcm_sharded* s, const float* scene_lines, int64_t n_scene_lines, int64_t max_tmpl_lines,
                         int64_t max_scene_lines, int optimizer, int64_t batch_size, fdcm_match** out, int64_t* n_out) {
+    DeviceGuard guard;
     return guarded_s([&] {
         if (!s || !out || !n_out) throw std::string("null argument");
         *out = nullptr; *n_out = 0;
-        run_shards(s, scene_lines, n_scene_lines, max_tmpl_lines, max_scene_lines, optimizer, batch_size, false, -1, 1.f, 0);
-        const int64_t total = gather_to_first(s);
-        *out = download(s, total);
-        *n_out = total;
+        const int64_t t = submit_frame(s, make_job(scene_lines, n_scene_lines, max_tmpl_lines, max_scene_lines, optimizer, batch_size,
+                                                   false, -1, 1.f, 0));
+        collect_frame(s, t, out, n_out);
     });
 }
 
 int fdcm_sharded_search_topk(fdcm_sharded* s, const float* scene_lines, int64_t n_scene_lines, int64_t max_tmpl_lines,
                              int64_t max_scene_lines, int optimizer, int64_t batch_size, int penalty, float tau, int64_t k,
                              fdcm_match** out, int64_t* n_out) {
+    DeviceGuard guard;
     return guarded_s([&] {
         if (!s || !out || !n_out) throw std::string("null argument");
-        if (penalty < -1 || penalty > FDCM_EXPONENTIAL_PENALTY) throw std::string("unknown penalty");
-        if (k < 0) throw std::string("k must be >= 0");
         *out = nullptr; *n_out = 0;
-        run_shards(s, scene_lines, n_scene_lines, max_tmpl_lines, max_scene_lines, optimizer, batch_size, true, penalty, tau, k);
-        const int64_t total = gather_to_first(s);  // at most k records per shard cross the links
-        fdcm_match* all = download(s, total);
-        // every shard's list is ascending by score with ties in positional order, and the lists arrive in shard order:
-        // a stable sort by score keeps ties in (shard, position) = global positional order
-        std::stable_sort(all, all + total, [](const fdcm_match& a, const fdcm_match& b) {
-            return fdcm::ordered_key_host(a.score) < fdcm::ordered_key_host(b.score);
-        });
-        *out = all;
-        *n_out = std::min<int64_t>(k, total);
+        const int64_t t = submit_frame(s, make_job(scene_lines, n_scene_lines, max_tmpl_lines, max_scene_lines, optimizer, batch_size,
+                                                   true, penalty, tau, k));
+        collect_frame(s, t, out, n_out);
     });
 }
 

@@ -162,6 +162,9 @@ class FrameGatherer:
             import ctypes as C
             from .engine import _adopt_matches
             out, n = C.c_void_p(), C.c_int64()
+            # the library launches on ITS thread-local device: select the buffers' one (it defaults to 0, and this may be
+            # another thread than the one that created the handles)
+            _capi.check(_capi.lib().fdcm_set_device(self.device.index if self.device.index is not None else torch.cuda.current_device()))
             _capi.check(_capi.lib().fdcm_blocks_to_host(C.c_void_p(self.recv.data_ptr()), self.world, self.cap,
                                                         C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream),
                                                         C.byref(out), C.byref(n)))

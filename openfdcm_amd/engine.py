@@ -320,6 +320,30 @@ class ShardedEngine:
                                                        -1 if penalty is None else penalty, tau, k, C.byref(out), C.byref(n)))
         return _adopt_matches(out, n.value)
 
+    def set_frames_in_flight(self, n_frames):
+        """Frame slots per device (1..16); only while no frame is in flight."""
+        capi.check(capi.lib().fdcm_sharded_set_frames_in_flight(self._h, int(n_frames)))
+
+    def submit(self, scene, max_tmpl_lines, max_scene_lines, optimizer=capi.BATCH_OPTIMIZE, batch_size=10, k=None,
+               penalty=None, tau=1.0, prepared=False):
+        """Queue one frame on every device and return its ticket (k given: top-k mode)."""
+        rec = scene if prepared else capi.as_records(scene)
+        t = C.c_int64()
+        if k is None:
+            capi.check(capi.lib().fdcm_sharded_submit(self._h, capi.fptr(rec) if rec.size else None, rec.shape[0], max_tmpl_lines,
+                                                      max_scene_lines, optimizer, batch_size, C.byref(t)))
+        else:
+            capi.check(capi.lib().fdcm_sharded_submit_topk(self._h, capi.fptr(rec) if rec.size else None, rec.shape[0],
+                                                           max_tmpl_lines, max_scene_lines, optimizer, batch_size,
+                                                           -1 if penalty is None else penalty, tau, k, C.byref(t)))
+        return t.value
+
+    def wait(self, ticket):
+        """Collect a frame: its exchange runs here while the devices compute the frames submitted after it."""
+        out, n = C.c_void_p(), C.c_int64()
+        capi.check(capi.lib().fdcm_sharded_wait(self._h, int(ticket), C.byref(out), C.byref(n)))
+        return _adopt_matches(out, n.value)
+
     def timing(self, shard=0):
         bt, st = capi.BuildTiming(), capi.SearchTiming()
         capi.check(capi.lib().fdcm_sharded_last_timing(self._h, shard, C.byref(bt), C.byref(st)))

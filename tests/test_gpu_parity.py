@@ -619,6 +619,111 @@ def test_sharded_engine_one_device(amd, always_collective):
     eng.close()
 
 
+def test_sharded_engine_frames_in_flight(amd):
+    """fdcm_sharded_submit / _wait with three frame slots per device and the RCCL exchange: six different scenes are in
+    flight three at a time, every collected frame equals the blocking single-device search of its own scene (a slot or
+    frame mix-up in the exchange would show), top-k frames interleaved, tickets checked."""
+    from openfdcm_amd import synthetic, _capi
+    from openfdcm_amd.engine import DeviceFeatureMap, DeviceTemplates, ShardedEngine, search_raw, topk
+    S = 256
+    tmpls = synthetic.templates(40, 11, S, 21)
+    scenes = [synthetic.scene(S, 30 + 7 * i, 40 + i) for i in range(6)] + [np.zeros((4, 0), np.float32)]
+    eng = ShardedEngine(tmpls, n_devices=1, depth=16, coeff=5.0, padding=1.0, distance=O.L2_SQUARED, always_collective=True)
+    eng.set_frames_in_flight(3)
+    fm = DeviceFeatureMap.build(scenes[0], depth=16, coeff=5.0, padding=1.0, distance=O.L2_SQUARED)
+    tset = DeviceTemplates(tmpls)
+    want, want_top = [], []
+    for sc in scenes:
+        fm.rebuild(sc)
+        want.append(np.array(search_raw(fm, tset, sc, 4, 4, _capi.BATCH_OPTIMIZE, 10), copy=True))
+        want_top.append(np.array(topk(fm, tset, 17, 1, 1.5), copy=True) if sc.shape[1] else want[-1][:0])
+    order = list(range(len(scenes))) * 2
+    pending = []
+    for step, i in enumerate(order):
+        if len(pending) == 3:
+            t, j, top = pending.pop(0)
+            got = eng.wait(t)
+            assert got.tobytes() == (want_top[j] if top else want[j]).tobytes(), (t, j, top)
+        top = step % 3 == 1
+        t = eng.submit(scenes[i], 4, 4, _capi.BATCH_OPTIMIZE, 10, k=17 if top else None, penalty=1, tau=1.5)
+        assert t == step
+        pending.append((t, i, top))
+    with pytest.raises(_capi.FdcmError, match="not been waited for"):
+        eng.submit(scenes[0], 4, 4)
+    with pytest.raises(_capi.FdcmError, match="in flight"):
+        eng.set_frames_in_flight(2)
+    for t, j, top in pending:
+        assert eng.wait(t).tobytes() == (want_top[j] if top else want[j]).tobytes(), (t, j, top)
+    with pytest.raises(_capi.FdcmError, match="ticket"):
+        eng.wait(0)
+    eng.set_frames_in_flight(1)
+    assert eng.search(scenes[2], 4, 4).tobytes() == want[2].tobytes()
+    eng.close()
+
+
+def test_sharded_engine_leaves_the_callers_device_alone(amd):
+    """fdcm_sharded_* switch devices on the caller's thread for allocations and the exchange; the library's
+    thread-local device and HIP's current device are what they were when a call returns."""
+    import ctypes as C
+    from openfdcm_amd import synthetic, _capi
+    from openfdcm_amd.engine import ShardedEngine
+    hip = C.CDLL("libamdhip64.so")
+    def current():
+        a, b = C.c_int(-1), C.c_int(-1)
+        _capi.check(_capi.lib().fdcm_get_device(C.byref(a)))
+        assert hip.hipGetDevice(C.byref(b)) == 0
+        return a.value, b.value
+    n = C.c_int()
+    _capi.check(_capi.lib().fdcm_device_count(C.byref(n)))
+    last = n.value - 1
+    _capi.check(_capi.lib().fdcm_set_device(0))
+    before = current()
+    tmpls = synthetic.templates(6, 7, 128, 3)
+    eng = ShardedEngine(tmpls, devices=[last], depth=8, coeff=5.0, padding=1.0, always_collective=True)
+    assert current() == before
+    scene = synthetic.scene(128, 20, 5)
+    eng.search(scene, 3, 3)
+    assert current() == before
+    eng.search_topk(scene, 3, 3, 5, penalty=0)
+    assert current() == before
+    eng.close()
+    assert current() == before
+
+
+def test_sharded_engine_several_devices(amd):
+    """fdcm_sharded_* with more than one device -- ncclCommInitAll over several devices, workers per device,
+    cross-device send/recv into the gathered array at per-shard offsets, the top-k merge across shards, uneven and empty
+    shards (fewer templates than devices).  Needs >= 2 GPUs: skipped on the one-GPU test box (the feature stays marked
+    UNVERIFIED on multi-GPU hardware in README/INTEGRATION until this has run on such a node)."""
+    import ctypes as C
+    from openfdcm_amd import synthetic, _capi
+    from openfdcm_amd.engine import DeviceFeatureMap, DeviceTemplates, ShardedEngine, search_raw, topk
+    n = C.c_int()
+    _capi.check(_capi.lib().fdcm_device_count(C.byref(n)))
+    if n.value < 2:
+        pytest.skip("needs at least two GPUs")
+    nd = min(n.value, 8)
+    S = 256
+    scenes = [synthetic.scene(S, 50, 61), synthetic.scene(S, 35, 62)]
+    for T in (nd * 5 + 3, nd - 1, 1):  # uneven shards; fewer templates than devices (empty shards)
+        tmpls = synthetic.templates(T, 12, S, 70 + T)
+        eng = ShardedEngine(tmpls, n_devices=nd, depth=16, coeff=5.0, padding=1.0, distance=O.L2)
+        eng.set_frames_in_flight(2)
+        _capi.check(_capi.lib().fdcm_set_device(0))
+        tset = DeviceTemplates(tmpls)
+        fm = DeviceFeatureMap.build(scenes[0], depth=16, coeff=5.0, padding=1.0, distance=O.L2)
+        tickets = [(eng.submit(sc, 4, 4, _capi.BATCH_OPTIMIZE, 10), sc, None) for sc in scenes]
+        for t, sc, _ in tickets:
+            fm.rebuild(sc)
+            want = search_raw(fm, tset, sc, 4, 4, _capi.BATCH_OPTIMIZE, 10)
+            assert eng.wait(t).tobytes() == want.tobytes(), (T, t)
+            for k in (1, 7, len(want) + 3):
+                assert eng.search_topk(sc, 4, 4, k, penalty=1, tau=1.5).tobytes() == topk(fm, tset, k, 1, 1.5).tobytes(), (T, k)
+        info = eng.info()
+        assert info["shard_begin"][0] == 0 and info["shard_begin"][-1] == T and info["collectives"] > 0
+        eng.close()
+
+
 def test_sharded_engine_rejects_bad_devices(amd):
     from openfdcm_amd import synthetic, _capi
     from openfdcm_amd.engine import ShardedEngine
