@@ -77,8 +77,9 @@ def pmc_traffic(config):
 
 
 def cpu_baseline(cfg, scene, tmpls, sample_templates, reps):
-    """Oracle on the host cores: one build + search over the first `sample_templates` templates, median of `reps`.
-    Returns (json object, the oracle's match records of the sample)."""
+    """Oracle on the host cores: one build + search over the first `sample_templates` templates (by default all of
+    them: nothing is scaled), median of `reps`.  The oracle's workers are a long-lived pool, as the reference's
+    BS::thread_pool is, so thread start-up is not what is timed.  Returns (json object, the oracle's match records)."""
     from oracle import oracle as O
     cores = os.cpu_count() or 1
     sub = tmpls[:sample_templates]
@@ -96,8 +97,9 @@ def cpu_baseline(cfg, scene, tmpls, sample_templates, reps):
     frame = t_build + t_search * scale
     return {
         "value": len(m) * scale / frame, "unit": "matches/s", "cores": cores, "kind": "port",
-        "sample": f"1 DT3 build ({t_build * 1e3:.0f} ms) + search of the first {len(sub)} of {len(tmpls)} templates "
-                  f"({t_search * 1e3:.0f} ms, scaled x{scale:g}) with {cores} threads, 1 warm-up + median of {reps} runs "
+        "sample": f"1 DT3 build ({t_build * 1e3:.0f} ms) + search of " + (f"all {len(tmpls)} templates ({t_search * 1e3:.0f} ms)" if scale == 1
+                  else f"the first {len(sub)} of {len(tmpls)} templates ({t_search * 1e3:.0f} ms, scaled x{scale:g})") +
+                  f" with {cores} threads (a long-lived pool), 1 warm-up + median of {reps} runs "
                   f"(~{(t_build + t_search) * cores * (reps + 1):.0f} core-seconds in all); the oracle is a restatement "
                   "(the reference cannot be built here) that omits the reference's two O(V) deep copies",
         "dt3_build_ms": t_build * 1e3, "search_matches_per_s": len(m) / t_search,
@@ -129,8 +131,15 @@ def main():
     ap.add_argument("--single-frames", type=int, default=30,
                     help="blocking frames measured after the timed region for the roofline objects (0 = skip)")
     ap.add_argument("--templates", type=int, default=None, help="templates per GPU (default: the config's)")
-    ap.add_argument("--cpu-sample", type=int, default=100,
-                    help="templates in the CPU baseline / parity gate sample (0 = skip both)")
+    ap.add_argument("--cpu-sample", type=int, default=-1,
+                    help="templates in the CPU baseline / parity gate (default -1 = all of the rank's; 0 = skip both)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: the config's per-GPU template count on every rank; strong: the config's TOTAL template count "
+                         "(BASELINE.md section 5: 1/2/4/8 GPUs on config 2' itself) cut into N shards")
+    ap.add_argument("--scenes", type=int, default=None,
+                    help="distinct scenes cycled through the frames (seeds 1..n; default 1, 4 with --force-dist).  With more "
+                         "than one, EVERY collected frame of the timed region is checked against the oracle's records of its "
+                         "own scene after the run (a frame/slot mix-up in the pipeline or the gather would show)")
     ap.add_argument("--cpu-reps", type=int, default=5, help="CPU baseline runs (median)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -159,11 +168,18 @@ def main():
 
     cfg = dict(synthetic.CONFIGS[args.config])
     per_gpu = args.templates or PER_GPU[args.config]
-    scene = synthetic.scene(cfg["S"], cfg["scene_lines"], 1)
-    # weak scaling: every rank owns `per_gpu` templates of a global list of world * per_gpu
-    all_templates = synthetic.templates(per_gpu * world, cfg["n"], cfg["S"], 2)
+    n_scenes = args.scenes or (4 if args.force_dist else 1)
+    scenes = [synthetic.scene(cfg["S"], cfg["scene_lines"], 1 + i) for i in range(n_scenes)]
+    scene = scenes[0]
+    # weak scaling: every rank owns `per_gpu` templates of a global list of world * per_gpu;
+    # strong scaling: the global list is the config's own (per_gpu templates in all), cut into `world` contiguous shards
+    total_templates = per_gpu * world if args.scaling == "weak" else per_gpu
+    all_templates = synthetic.templates(total_templates, cfg["n"], cfg["S"], 2)
     searcher = ShardedSearcher(all_templates, rank, world, device)
-    rec = _capi.as_records(scene)
+    recs = [_capi.as_records(sc) for sc in scenes]
+    rec = recs[0]
+    frame_no = [0]        # frames submitted so far (selects the scene)
+    kept = []             # (scene index, matches) of every timed frame when several scenes are cycled
     F = max(1, args.frames)
     pipe = ShardedPipeline.create(searcher, rec.shape[0], cfg["depth"], 5.0, 1.0, cfg["distance"], 4, 4,
                                   _capi.BATCH_OPTIMIZE, 10, slots=F, gather=use_dist)
@@ -178,13 +194,20 @@ def main():
             if len(pipe.pending) == F:
                 collect(record)
             submit_t.append(time.perf_counter())
-            pipe.submit(rec)
+            scene_q.append(frame_no[0] % n_scenes)
+            pipe.submit(recs[scene_q[-1]])
+            frame_no[0] += 1
         while pipe.pending:
             collect(record)
+
+    scene_q = []
 
     def collect(record):
         res = pipe.collect()
         t_sub = submit_t.pop(0)
+        si = scene_q.pop(0)
+        if record and n_scenes > 1 and res is not None:
+            kept.append((si, res))
         if record:
             latency.append(time.perf_counter() - t_sub)
             bt, stt = pipe.pipe.last_build_timing, pipe.pipe.last_search_timing
@@ -196,8 +219,9 @@ def main():
             acc["evaluations"] = stt["evaluations"]
             acc["frames"] += 1
             if res is not None:
-                acc["n_matches"] = len(res)
+                acc["n_matches"] += len(res)
                 acc["last"] = res
+                acc["last_scene"] = si
 
     def fence():
         if use_dist:
@@ -225,7 +249,8 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    n_matches = acc["n_matches"]
+    total_matches = acc["n_matches"]            # of all K timed frames (they differ when scenes are cycled)
+    n_matches = total_matches / max(1, args.steps)
     gpu_last = None if acc["last"] is None else np.array(acc["last"], copy=True)
 
     # untimed extra: blocking frames (one in flight, the GPU to itself) for the roofline objects
@@ -260,13 +285,16 @@ def main():
         dname = DIST_NAMES[cfg["distance"]]
         out = {
             "metric": "template matches/sec (DT3 build + DefaultMatch/BatchOptimize search per frame)",
-            "value": n_matches * K / elapsed, "unit": "matches/s", "n_gpus": world, "steps": K,
-            "warmup": args.warmup, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
+            "value": total_matches / elapsed, "unit": "matches/s", "n_gpus": world, "steps": K,
+            "warmup": args.warmup, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"BASELINE config {args.config.replace('p', chr(39))}: {cfg['S']}x{cfg['S']} scene, "
-                                   f"{cfg['scene_lines']} lines, depth {cfg['depth']}, {dname}, {per_gpu} templates x "
-                                   f"{cfg['n']} lines per GPU, DefaultSearch(4,4), BatchOptimize(10)",
-                       "templates_total": per_gpu * world, "matches_per_step": n_matches, "frames_in_flight": F,
+                                   f"{cfg['scene_lines']} lines, depth {cfg['depth']}, {dname}, " +
+                                   (f"{per_gpu} templates x {cfg['n']} lines per GPU" if args.scaling == "weak" else
+                                    f"{per_gpu} templates x {cfg['n']} lines in all, cut into {world} shard(s)") +
+                                   ", DefaultSearch(4,4), BatchOptimize(10)",
+                       "templates_total": total_templates, "matches_per_step": n_matches, "frames_in_flight": F,
+                       "distinct_scenes": n_scenes,
                        "parallelism": f"template shards x{world}, DT3 replicated, 1 RCCL gather per frame",
                        "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES")},
             "frame_latency_ms": {"p50": float(np.percentile(lat, 50)), "p95": float(np.percentile(lat, 95)),
@@ -275,7 +303,7 @@ def main():
                                  # normal spans, a stalled GPU a long one)
                                  "slowest": (lambda i: {"frame": int(i), "latency": frame_log[i][0], "build_span": frame_log[i][1],
                                                         "search_span": frame_log[i][2], "search_kernels": frame_log[i][3]})(int(np.argmax(lat)))},
-            "templates_per_s": per_gpu * world * K / elapsed,
+            "templates_per_s": total_templates * K / elapsed,
             "dt3_build_ms": avg["total_ms"], "search_ms": acc["search_total_ms"] / K,
             "in_timed_region": {"note": f"per-launch HIP-event times with {F} frames in flight: launches of concurrent "
                                         "frames share the CUs, so these exceed ms_per_step and the blocking figures",
@@ -310,14 +338,30 @@ def main():
                                               "random 4-byte gathers move a 64-byte sector each, informational"}
             out["single_frame_ms"] = single["frame_ms"]
             out["single_frame_matches_per_s"] = n_matches / (single["frame_ms"] * 1e-3)
-        if args.cpu_sample > 0 and world == 1:  # rank 0 at N=1 only
-            sample = min(args.cpu_sample, per_gpu)
-            out["cpu_baseline"], want = cpu_baseline(cfg, scene, all_templates[:per_gpu], sample, args.cpu_reps)
-            got = gpu_last[gpu_last["tmpl_idx"] < sample]
-            same = len(got) == len(want) and got.tobytes() == np.asarray(want, dtype=_capi.MATCH_DTYPE).tobytes()
+        if args.cpu_sample != 0 and world == 1:  # rank 0 at N=1 only
+            sample = per_gpu if args.cpu_sample < 0 else min(args.cpu_sample, per_gpu)
+            out["cpu_baseline"], want0 = cpu_baseline(cfg, scene, all_templates[:per_gpu], sample, args.cpu_reps)
+
+            def same_as_oracle(got_all, want):
+                got = got_all[got_all["tmpl_idx"] < sample]
+                return len(got) == len(want) and got.tobytes() == np.asarray(want, dtype=_capi.MATCH_DTYPE).tobytes()
+
+            if n_scenes == 1:
+                same, checked = same_as_oracle(gpu_last, want0), 1
+                n_rec = len(want0)
+            else:  # every timed frame against the oracle's records of ITS scene
+                from oracle import oracle as O
+                cores = os.cpu_count() or 1
+                wants = [want0]
+                for sc in scenes[1:]:
+                    ofm = O.build(sc, depth=cfg["depth"], coeff=5.0, padding=1.0, distance=cfg["distance"], nthreads=cores)
+                    wants.append(O.search(ofm, all_templates[:sample], sc, 4, 4, kind=O.BATCH_OPTIMIZE, batch=10, nthreads=cores))
+                same = len(kept) == K and all(same_as_oracle(np.asarray(res), wants[si]) for si, res in kept)
+                checked, n_rec = len(kept), sum(len(wants[si]) for si, _ in kept)
             out["parity_gate"] = "ok" if same else "FAILED"
-            out["parity_gate_detail"] = (f"match records of the first {sample} templates ({len(want)} records) of the last "
-                                         "timed frame against the CPU oracle, bit for bit")
+            out["parity_gate_detail"] = (f"match records of the first {sample} templates of "
+                                         f"{'the last timed frame' if n_scenes == 1 else f'all {checked} timed frames ({n_scenes} scenes cycled)'}"
+                                         f" ({n_rec} records) against the CPU oracle, bit for bit")
             gate_failed = not same
     pipe.close()
     if use_dist:

@@ -150,6 +150,8 @@ struct fdcm_featuremap {
     fdcm::DevBuf s_counter;
     fdcm::PinnedBuf s_stage;
     fdcm::PinnedBuf s_cnt;   // the search's counters, written by k_scatter (device-output searches)
+    fdcm::DevBuf s_bins;     // orientation bins per candidate line from the host libm (only when it differs from the device's atanf)
+    fdcm::PinnedBuf s_bins_stage;
     fdcm::Timing timing;
     fdcm_build_timing last_build = {};
     fdcm_search_timing last_search = {};

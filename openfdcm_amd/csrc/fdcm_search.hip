@@ -21,9 +21,11 @@
 // every decision -- are the reference's bit for bit; translations scored speculatively but never
 // reached by the rule are simply not read.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstring>
 #include <numeric>
+#include <thread>
 
 #include "fdcm_internal.h"
 #include "fdcm_score.h"
@@ -63,6 +65,7 @@ struct SearchParams {
     int nblocks;                    // k_search workgroups
     int xcd_parts;                  // 1: every XCD takes its own contiguous part of the work list
     int lds_lines;                  // capacity (lines) of the LDS template / aligned-line areas
+    const unsigned short* host_bins; // [candidate][lds_lines] orientation bins computed with the host libm, or null (see run_search)
     // outputs
     fdcm_match* records;
     int* flags;
@@ -377,8 +380,13 @@ __global__ void __launch_bounds__(256, FDCM_SEARCH_WPE) k_search(const SearchPar
         const float* p = s_tl + 4 * i;
         const float x1 = (T[0] * p[0] + T[1] * p[1]) + T[2], y1 = (T[3] * p[0] + T[4] * p[1]) + T[5];
         const float x2 = (T[0] * p[2] + T[1] * p[3]) + T[2], y2 = (T[3] * p[2] + T[4] * p[3]) + T[5];
-        const float angle = atanf_glibc((y2 - y1) / (x2 - x1));  // getAngle, math.h:295-299
-        const int bin = closest_orientation(s_keys, P.m, angle);  // dt3cpu.cpp:144-148
+        int bin;
+        if (P.host_bins) {
+            bin = (int)P.host_bins[(size_t)cand * P.lds_lines + i];
+        } else {
+            const float angle = atanf_glibc((y2 - y1) / (x2 - x1));  // getAngle, math.h:295-299
+            bin = closest_orientation(s_keys, P.m, angle);  // dt3cpu.cpp:144-148
+        }
         float* d = L + 5 * i;
         d[0] = x1; d[1] = y1; d[2] = x2; d[3] = y2; d[4] = __int_as_float(bin);
         mnx = std_min(mnx, std_min(x1, x2)); mxx = std_max(mxx, std_max(x1, x2));
@@ -530,15 +538,13 @@ void run_search(fdcm_featuremap* fm, const fdcm_templates* t, const float* scene
     fm->last_search = fdcm_search_timing{};
     // early-outs of search<DefaultMatch>, defaultmatch.cpp:40-41
     if (t->T == 0 || n_scene == 0 || (fm->W == 0 && fm->H == 0)) return;
-    {
-        // The orientation bins of the aligned template lines come from the device restatement of glibc 2.35's atanf,
-        // the scene's from the host libm (as in the reference): on a host whose libm differs the two would
-        // silently disagree, so the first search checks a sample (every 65537th bit pattern, a few ms) and refuses.
-        static const int64_t libm_mismatches = fdcm_selftest_atanf(0, 65537, (1ull << 32) / 65537);
-        if (libm_mismatches != 0)
-            throw std::string("this host's libm atanf differs from the device restatement (glibc 2.35 fdlibm) on ") +
-                std::to_string(libm_mismatches) + " sampled inputs: orientation bins would not match the reference's";
-    }
+    // The orientation bins of the aligned template lines come from the device restatement of glibc 2.35's atanf, the
+    // scene's from the host libm (as in the reference): on a host whose libm differs (a newer glibc ships a correctly
+    // rounded atanf) the two would silently disagree.  The first search checks a sample (every 65537th bit pattern, a
+    // few ms); on a mismatch the bins of every candidate's lines are computed on the host instead -- same transform,
+    // this machine's atanf, a few host threads, overlapping the build that is still running on the device -- so that
+    // parity is defined against the box's own libm, as the reference's would be.  FDCM_FORCE_HOST_BINS=1 forces it.
+    static const bool host_bins_needed = fdcm_selftest_atanf(0, 65537, (1ull << 32) / 65537) != 0 || getenv("FDCM_FORCE_HOST_BINS") != nullptr;
     FDCM_HIP(hipSetDevice(fm->device));
     if (!fm->stream) FDCM_HIP(hipStreamCreateWithFlags(&fm->stream, hipStreamNonBlocking));
     if (!fm->timing.created) {
@@ -657,6 +663,56 @@ void run_search(fdcm_featuremap* fm, const fdcm_templates* t, const float* scene
     } else {
         P.work = nullptr;
         P.nblocks = (int)((size_t)t->T * P.bpt);
+    }
+    if (host_bins_needed) {
+        if (fm->m > 65535) throw std::string("host-side orientation bins need depth <= 65535");
+        const size_t stride = (size_t)P.lds_lines;
+        fm->s_bins_stage.reserve((size_t)ncand * stride * sizeof(unsigned short));
+        fm->s_bins.reserve((size_t)ncand * stride * sizeof(unsigned short));
+        unsigned short* hb = (unsigned short*)fm->s_bins_stage.p;
+        const float* keys = fm->keys.data();
+        const int mkeys = (int)fm->m;
+        std::vector<float> sorted_len((size_t)n_s);
+        for (int i = 0; i < n_s; ++i) sorted_len[i] = slen[sidx[i]];
+        const unsigned nthreads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+        std::vector<std::thread> th;
+        std::atomic<int64_t> next{0};
+        const fdcm_templates* tt = t;
+        for (unsigned w = 0; w < nthreads; ++w)
+            th.emplace_back([&, tt] {
+                for (int64_t ti; (ti = next.fetch_add(1)) < tt->T;) {
+                    const int64_t l0 = tt->offsets[ti];
+                    const int n_t = (int)(tt->offsets[ti + 1] - l0);
+                    const int jmax = (int)std::min<int64_t>(n_t, maxT);
+                    for (int j = 0; j < jmax; ++j) {  // establishSearchStrategy<DefaultSearch>, as k_pairs
+                        const int tl_local = tt->sorted[(size_t)l0 + j];
+                        const float tlen = tt->lengths[(size_t)l0 + tl_local];
+                        const int centre = binary_search_greater(sorted_len.data(), n_s, tlen);
+                        int rb, re;
+                        centered_range(centre, n_s, (int)maxS, rb, re);
+                        for (int wi = 0; wi < window; ++wi) {
+                            const int scene_idx = (int)sidx[rb + wi];
+                            float T1[6], T2[6];
+                            align_pair(&tt->lines[(size_t)(l0 + tl_local) * 4], scene + (size_t)scene_idx * 4, T1, T2);
+                            for (int flip = 0; flip < 2; ++flip) {
+                                const float* T = flip ? T2 : T1;
+                                const long long cand = coff[ti] + 2ll * (j * window + wi) + flip;
+                                unsigned short* out = hb + (size_t)cand * stride;
+                                for (int i = 0; i < n_t; ++i) {
+                                    const float* p = &tt->lines[(size_t)(l0 + i) * 4];
+                                    const float x1 = (T[0] * p[0] + T[1] * p[1]) + T[2], y1 = (T[3] * p[0] + T[4] * p[1]) + T[5];
+                                    const float x2 = (T[0] * p[2] + T[1] * p[3]) + T[2], y2 = (T[3] * p[2] + T[4] * p[3]) + T[5];
+                                    const float angle = std::atan((y2 - y1) / (x2 - x1));  // the host libm, like the scene's bins
+                                    out[i] = (unsigned short)closest_orientation(keys, mkeys, angle);
+                                }
+                            }
+                        }
+                    }
+                }
+            });
+        for (auto& x : th) x.join();
+        FDCM_HIP(hipMemcpyAsync(fm->s_bins.p, hb, (size_t)ncand * stride * sizeof(unsigned short), hipMemcpyHostToDevice, st));
+        P.host_bins = fm->s_bins.as<unsigned short>();
     }
     hipLaunchKernelGGL(k_search, dim3((unsigned)P.nblocks), dim3(256), lds, st, P);
     fdcm_match* dst = out_device;

@@ -22,6 +22,8 @@
 #include <algorithm>
 #include <array>
 #include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <cfloat>
 #include <cmath>
 #include <cstdint>
@@ -534,15 +536,57 @@ struct Dt3 {
     long W = 0, H = 0;
 };
 
-// Minimal task pool with the reference's granularity (one task per item, dynamic pick-up).
+// Task pool with the reference's granularity (one task per item, dynamic pick-up).  The reference shares one
+// BS::thread_pool between calls (batchoptimize.h:11,22: a shared_ptr), so thread start-up is not part of a timed
+// search there; likewise the workers here are long-lived (one process-wide pool that grows to the largest thread count
+// asked for) and a call hands them a job and waits.
+class TaskPool {
+    std::mutex mu;
+    std::condition_variable cv_job, cv_done;
+    std::vector<std::thread> workers;
+    const std::function<void(long)>* fn = nullptr;
+    std::atomic<long> next{0};
+    long n = 0;
+    unsigned long generation = 0;
+    int want = 0, active = 0;   // workers allowed to join the current job / still running it
+    bool quit = false;
+    void worker(int id) {
+        unsigned long seen = 0;
+        std::unique_lock<std::mutex> lk(mu);
+        while (true) {
+            cv_job.wait(lk, [&] { return quit || (generation != seen && id < want); });
+            if (quit) return;
+            seen = generation;
+            const std::function<void(long)>* f = fn;
+            const long total = n;
+            lk.unlock();
+            for (long i; (i = next.fetch_add(1)) < total;) (*f)(i);
+            lk.lock();
+            if (--active == 0) cv_done.notify_all();
+        }
+    }
+public:
+    void run(long count, int nthreads, const std::function<void(long)>& f) {
+        static std::mutex one_job;  // one job at a time (callers are the tests and the bench: sequential)
+        std::lock_guard<std::mutex> job(one_job);
+        std::unique_lock<std::mutex> lk(mu);
+        const int nt = (int)std::min<long>(nthreads, count);
+        while ((int)workers.size() < nt) { const int id = (int)workers.size(); workers.emplace_back([this, id] { worker(id); }); }
+        fn = &f; n = count; next.store(0); want = nt; active = nt; ++generation;
+        cv_job.notify_all();
+        cv_done.wait(lk, [&] { return active == 0; });
+        fn = nullptr; want = 0;
+    }
+    ~TaskPool() {
+        { std::lock_guard<std::mutex> lk(mu); quit = true; }
+        cv_job.notify_all();
+        for (auto& t : workers) t.join();
+    }
+};
 static inline void parallelFor(long n, int nthreads, const std::function<void(long)>& fn) {
     if (nthreads <= 1 || n <= 1) { for (long i = 0; i < n; ++i) fn(i); return; }
-    std::atomic<long> next{0};
-    std::vector<std::thread> th;
-    int nt = (int)std::min<long>(nthreads, n);
-    for (int t = 0; t < nt; ++t)
-        th.emplace_back([&] { for (long i; (i = next.fetch_add(1)) < n;) fn(i); });
-    for (auto& t : th) t.join();
+    static TaskPool* pool = new TaskPool();  // never destroyed: no join at process exit
+    pool->run(n, nthreads, fn);
 }
 
 // buildCpuFeaturemap<D>, dt3cpu.h:174-234.

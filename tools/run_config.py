@@ -20,6 +20,10 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--check", default="full", choices=["none", "full", "sample"])
     ap.add_argument("--search", action="store_true")
+    ap.add_argument("--perturb", action="store_true",
+                    help="also report the build time of a handle's FIRST build, of rebuilds with the SAME scene and of rebuilds "
+                         "with a CHANGED scene every time (alternately: every line jittered by up to 3 pixels, and a new seed): "
+                         "the L2 sweep takes its launch order from the handle's previous build")
     args = ap.parse_args()
     from openfdcm_amd import synthetic, _capi
     from openfdcm_amd.engine import DeviceFeatureMap, DeviceTemplates, search_raw
@@ -36,6 +40,32 @@ def main():
     kern = sum(avg[k] for k in avg if k != "total_ms")
     out = {"config": args.config, "V_MB": V / 1e6, "stage_ms": avg, "kernels_ms": kern,
            "GBps_7V": 7 * V / (kern * 1e-3) / 1e9, "frac_of_8TBps": 7 * V / (kern * 1e-3) / 8e12}
+    if args.perturb:
+        def kern(t):
+            return sum(v for k, v in t.items() if k != "total_ms")
+        firsts = []
+        for i in range(5):  # fresh handles: no history
+            d2 = DeviceFeatureMap.build(synthetic.scene(cfg["S"], cfg["scene_lines"], 1 + i), depth=cfg["depth"], coeff=5.0,
+                                        padding=1.0, distance=cfg["distance"])
+            firsts.append(kern(d2.build_timing()))
+            d2.close()
+        same, jitter, reseed = [], [], []
+        rng = np.random.default_rng(3)
+        base = np.array(scene, dtype=np.float32)
+        for i in range(args.reps):
+            dev.rebuild(scene); dev.rebuild(scene)
+            same.append(kern(dev.build_timing()))
+            j = base.copy()
+            j[:, 2:] += rng.uniform(-3, 3, size=j[:, 2:].shape).astype(np.float32)  # the two anchor lines keep the size
+            j = np.clip(j, 0, cfg["S"] - 1)
+            dev.rebuild(j)
+            jitter.append(kern(dev.build_timing()))
+            dev.rebuild(scene)
+            dev.rebuild(synthetic.scene(cfg["S"], cfg["scene_lines"], 100 + i))
+            reseed.append(kern(dev.build_timing()))
+        out["history"] = {"first_build_ms": float(np.median(firsts)), "same_scene_ms": float(np.median(same)),
+                          "jittered_scene_ms": float(np.median(jitter)), "new_scene_ms": float(np.median(reseed)),
+                          "note": "kernel spans; jittered = every line moved by up to 3 px since the previous build, new = another random scene of the same size"}
     if args.search:
         tmpls = synthetic.templates(T, cfg["n"], cfg["S"], 2)
         tset = DeviceTemplates(tmpls)
