@@ -76,6 +76,24 @@ def pmc_traffic(config):
     return float(sum(build)), os.path.basename(files[-1])
 
 
+def pmc_search_traffic(config):
+    """HBM bytes per launch of k_search from the same summary: (lower, upper) -- its 4-byte gathers produce 64-B and
+    128-B read requests that FETCH_SIZE tallies alike (tools/pmc_traffic.py, profiles/r03_fetch_calib.json), so the
+    truth lies between the raw counter and twice it; `traffic` reports the upper bound."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*pmc_traffic*config{config}*.json")))
+    if not files:
+        return None, None, "no PMC summary for this config under profiles/"
+    doc = json.load(open(files[-1]))
+    if doc.get("so_sha256_16") != so_hash():
+        return None, None, f"{os.path.basename(files[-1])} was measured on another build of libfdcm_hip.so"
+    for k, v in doc["kernels"].items():
+        if "k_search" in k:
+            lo = v.get("hbm_bytes_per_launch_lower", v["fetch_raw_bytes"] + v["write_bytes"])
+            return float(lo), float(v["hbm_bytes_per_launch"]), os.path.basename(files[-1])
+    return None, None, "k_search is not in the summary"
+
+
 def cpu_baseline(cfg, scene, tmpls, sample_templates, reps):
     """Oracle on the host cores: one build + search over the first `sample_templates` templates (by default all of
     them: nothing is scaled), median of `reps`.  The oracle's workers are a long-lived pool, as the reference's
@@ -329,10 +347,12 @@ def main():
                                            "HIP events on the feature map's own stream",
                                "stages": table}
             reads = 8.0 * acc["evaluations"] * cfg["n"]
+            s_lo, s_hi, s_src = pmc_search_traffic(args.config)
             ska = reads / (single["search_kernel_ms"] * 1e-3) / 1e9
             out["roofline_search"] = {"bound": "hbm", "kernel": "k_pairs + k_worklist + k_search + compaction",
                                       "achieved": ska, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ska / HBM_PEAK_GBS,
-                                      "traffic": None, "algorithmic_bytes_per_launch": reads,
+                                      "traffic": s_hi, "traffic_lower_bound": s_lo, "traffic_source": s_src,
+                                      "algorithmic_bytes_per_launch": reads,
                                       "avg_launch_ms": single["search_kernel_ms"],
                                       "note": "8 B x translations scored by the reference rule x lines per template; "
                                               "random 4-byte gathers move a 64-byte sector each, informational"}

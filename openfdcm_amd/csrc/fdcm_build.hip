@@ -185,6 +185,19 @@ __device__ __forceinline__ float column_value(unsigned long long wc, int pc, int
     return d >= (1 << 29) ? FLT_MAX : (SQUARED ? df * df : df);  // d < 2^14: df * df is the exact integer
 }
 
+// The squared value for a SEEDED column whose descriptor fields are wave-uniform (read with v_readlane): most columns of
+// a chunk have no seed inside the chunk's 64 rows (a line crosses a chunk in a few columns), and then the value is the
+// distance to the neighbour seeds alone -- 5 vector instructions behind a scalar branch instead of ~22.  (A seeded
+// column has a seed in some chunk, so a missing side is 2^30 away and the other one decides: never FLT_MAX here.)
+__device__ __forceinline__ float column_value_sq_seeded(unsigned long long wc, int pc, int nc, int lane, int y) {
+    if (wc == 0ull) {
+        const int d = min(y - pc, nc - y);
+        const float df = (float)d;
+        return df * df;
+    }
+    return column_value<true>(wc, pc, nc, lane, y);
+}
+
 __device__ __forceinline__ void desc_lane(const ColDesc& d, int j, unsigned long long& wc, int& pc, int& nc) {
     const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(d.word & 0xffffffffull), j);
     const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(d.word >> 32), j);
@@ -216,7 +229,7 @@ template <int R, int C, int SG, bool PF>
 __global__ void __launch_bounds__(256) k_pass2_l2(const ColDesc* __restrict__ desc, float* __restrict__ vol, int W,
                                                   int H, int HW64, long nwaves, int* __restrict__ sv,
                                                   float* __restrict__ sf, float* __restrict__ sz,
-                                                  const int* __restrict__ only_flagged) {
+                                                  const int* __restrict__ only_flagged, int il) {
     constexpr int NR = 4 * R;    // distinct rows per block
     __shared__ int r_v[C][NR];
     __shared__ float r_f[C][NR];
@@ -241,8 +254,11 @@ __global__ void __launch_bounds__(256) k_pass2_l2(const ColDesc* __restrict__ de
     const int y = c * 64 + bit;
     const long gid = wid * R + (lane & (R - 1));  // scratch row
     const uint4* dp = reinterpret_cast<const uint4*>(desc + ((size_t)k * HW64 + c) * W);
-    float* row = vol + (size_t)k * W * H + (y < H ? y : 0);  // element x at row[x * H]
+    // element x of the row: y-fastest row[x * H], or (il: behind the segmented sweep, whose fill writes the interleaved
+    // layout ivol_index that the propagation then reads with coalesced loads) row[((x / 4) * H) * 4 + x % 4]
+    float* row = il ? vol + (size_t)k * ivol_slice_floats(W, H) + (size_t)(y < H ? y : 0) * 4 : vol + (size_t)k * W * H + (y < H ? y : 0);
     const size_t H_ = (size_t)H, NT = (size_t)nwaves * R;
+    auto xoff = [&](int x) -> size_t { return il ? ((size_t)(x >> 2) * H_) * 4 + (size_t)(x & 3) : (size_t)x * H_; };
     const float inf = f_inf();
     // ---- envelope construction (imgproc.h:101-121)
     int tv = 0, uv = 0;
@@ -472,7 +488,7 @@ __global__ void __launch_bounds__(256) k_pass2_l2(const ColDesc* __restrict__ de
                     nbase = ob + dv * dv;
                 } else {
                     float t = 0.f;
-                    if (y < H) t = row[(size_t)nv_ * H_];  // rare read-back, consumed inside the branch
+                    if (y < H) t = row[xoff(nv_)];  // rare read-back, consumed inside the branch
                     asm volatile("v_mov_b32 %0, %1" : "=v"(nbase) : "v"(t));
                 }
             }
@@ -485,7 +501,7 @@ __global__ void __launch_bounds__(256) k_pass2_l2(const ColDesc* __restrict__ de
             fetch(kk + 2, bv, bf, bz);
         }
         const float dq = (float)(q - cv);  // dq * dq rounds like the reference's float(long(dq * dq))
-        if (mine && y < H && (PF || lane < R)) row[(size_t)q * H_] = base_val + dq * dq;
+        if (mine && y < H && (PF || lane < R)) row[xoff(q)] = base_val + dq * dq;
     }
 }
 
@@ -518,6 +534,13 @@ __global__ void __launch_bounds__(256) k_pass2_l2(const ColDesc* __restrict__ de
 //             imgproc.h:126-127), re-evaluated from the owner of pixel v found a few entries back
 //   k_fill    lane = (row, quarter of the pixels): pure fill from the owner list, entries staged through
 //             LDS in rounds of RE
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// store_unit_note: every 16-byte store of this file carries its whole offset in the lane (vector) offset, never in the
+// scalar offset operand.  A store of more than 8 bytes reads its data registers late, and a vector instruction that
+// overwrites them right behind it needs a wait state; the compiler inserts it only when the store has NO scalar
+// offset register.  With the group offset in an SGPR and a tight loop (k_l1_forward: store, then the shift of the
+// group registers) lanes 12-15 of every 16 stored the NEXT column's value in a group's first column -- at config 5
+// only (12 GB in flight: the store's data fetch is late), in 0.15 % of the pixels; found by the sampled-slice test.
 static constexpr int kSegMax = 8;
 static constexpr int kFillParts = 4;
 
@@ -620,8 +643,8 @@ __device__ __forceinline__ void env_phase(const ColDesc* __restrict__ desc, int 
                 desc_lane4(dv, j1, wc1, pc1, nc1);
                 desc_lane4(dv, j2, wc2, pc2, nc2);
                 const int u1 = wd * 64 + j1, u2 = wd * 64 + j2, du1 = u1 - x, du2 = u2 - x;
-                const float val1 = column_value<true>(wc1, pc1, nc1, lane, y) + (float)(du1 * du1);
-                const float val2 = column_value<true>(wc2, pc2, nc2, lane, y) + (float)(du2 * du2);
+                const float val1 = column_value_sq_seeded(wc1, pc1, nc1, lane, y) + (float)(du1 * du1);
+                const float val2 = column_value_sq_seeded(wc2, pc2, nc2, lane, y) + (float)(du2 * du2);
                 const bool b1 = val1 < best || (val1 == best && u1 < bestu);
                 best = b1 ? val1 : best;
                 bestu = b1 ? u1 : bestu;
@@ -701,7 +724,7 @@ __device__ __forceinline__ void env_phase(const ColDesc* __restrict__ desc, int 
                     dq.y = (unsigned)__builtin_amdgcn_readlane((int)dcur.y, j);
                     dq.z = (unsigned)__builtin_amdgcn_readlane((int)dcur.z, j);
                     dq.w = (unsigned)__builtin_amdgcn_readlane((int)dcur.w, j);
-                    float fq = column_value<true>(((unsigned long long)dq.y << 32) | dq.x, (int)dq.z, (int)dq.w, lane, y);
+                    float fq = column_value_sq_seeded(((unsigned long long)dq.y << 32) | dq.x, (int)dq.z, (int)dq.w, lane, y);
                     if (DBG && (expm & 4)) fq = (float)((lane * 7 + q * 13) & 1023);  // timing experiment: no pass-1 value
                     const bool act = q > cs && q <= ce;
                     const float qf = (float)q;
@@ -976,9 +999,15 @@ __device__ __forceinline__ void fill_phase(float* __restrict__ vol, int W, int H
     int idx = p == 0 ? 0 : B.partidx[(size_t)(p - 1) * NR + r];
     const int lc = B.lcount[r];
     const OwnEntry* own = B.own + r * (size_t)B.lslots;
-    const auto rs = __builtin_amdgcn_make_buffer_rsrc(vol + (size_t)k * W * H, 0, (unsigned)((size_t)W * H * 4), 0x00020000);
-    const unsigned vrow = y < H ? (unsigned)y * 4u : 0x80000000u;  // rows past the image: dropped stores
-    const int colB = H * 4;
+    // The fill writes the interleaved layout (ivol_index: 16 bytes = 4 neighbouring columns of one row) that the
+    // propagation reads: a lane collects the values of a group of 4 columns and stores them as one unit, 64 rows = 1 KB
+    // contiguous per wave (the y-fastest layout took a 4-byte store per pixel, and the propagation then loaded it in
+    // runs of 64 bytes: config 3 0.43 -> 0.37 ms there).  Parts start on a group (part_w is a multiple of 4).
+    const size_t sl = ivol_slice_floats(W, H);
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc(vol + (size_t)k * sl, 0, (unsigned)(sl * 4), 0x00020000);
+    const unsigned vrow = y < H ? (unsigned)y * 16u : 0x80000000u;  // rows past the image: dropped stores
+    const int grpB = H * 16;
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f;  // the group being collected (shift register: the newest value in g3)
     while (qcur < qend) {
         // entries [idx, idx + RE) of every row go to LDS; the round ends where the first row would need entry idx + RE
         unsigned pk[RE];
@@ -1004,10 +1033,21 @@ __device__ __forceinline__ void fill_phase(float* __restrict__ vol, int W, int H
             if (adv) { cpk = npk; cb = nb; ++a; }
             npk = f_pk[a + 1][tid]; nb = f_b[a + 1][tid];  // a + 1 <= RE - 1 because q < lim
             const float dq = (float)(q - (int)(cpk & 0xffffu));  // dq * dq rounds like float(long(dq * dq))
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(cb + dq * dq), rs, vrow, q * colB, 0);
+            g0 = g1; g1 = g2; g2 = g3; g3 = cb + dq * dq;
+            if ((q & 3) == 3) {  // wave-uniform
+                u32x4 out;
+                out.x = __float_as_uint(g0); out.y = __float_as_uint(g1); out.z = __float_as_uint(g2); out.w = __float_as_uint(g3);
+                __builtin_amdgcn_raw_buffer_store_b128(out, rs, vrow + (unsigned)((q >> 2) * grpB), 0, 0);  // (no scalar offset: see store_unit_note)
+            }
         }
         idx += a;
         qcur = qstop;
+    }
+    if (qend == W && (W & 3)) {  // the row's last group is partial: its columns past W are padding and hold 0
+        for (int q = W; q & 3; ++q) { g0 = g1; g1 = g2; g2 = g3; g3 = 0.f; }
+        u32x4 out;
+        out.x = __float_as_uint(g0); out.y = __float_as_uint(g1); out.z = __float_as_uint(g2); out.w = __float_as_uint(g3);
+        __builtin_amdgcn_raw_buffer_store_b128(out, rs, vrow + (unsigned)((W >> 2) * grpB), 0, 0);
     }
 }
 
@@ -1103,6 +1143,9 @@ __global__ void __launch_bounds__(256) k_fill(float* __restrict__ vol, int W, in
 // distanceTransform<float, L1> (imgproc.h:176-181): the sweeps along y are the descriptor
 // distance (exact integers), the forward sweep along x runs on it directly (imgproc.h:138-140)
 // and writes V; the backward sweep (imgproc.h:142-145) reads that and writes the result in place.
+// Both work on the interleaved layout (ivol_index: 16 bytes = 4 neighbouring columns of one row) that the propagation
+// reads: a lane moves one unit per group of 4 columns, 64 rows = 1 KB contiguous per wave operation (the y-fastest
+// form moved 4 bytes per lane and column; config 5: 8.1 -> measured in DESIGN.md).
 __global__ void __launch_bounds__(256) k_l1_forward(const ColDesc* __restrict__ desc, float* __restrict__ vol, int W,
                                                     int H, int HW64, long nwaves) {
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1113,10 +1156,12 @@ __global__ void __launch_bounds__(256) k_l1_forward(const ColDesc* __restrict__ 
     const int y = c * 64 + lane;
     const bool active = y < H;
     const ColDesc* dp = desc + ((size_t)k * HW64 + c) * W;
-    const auto rs = __builtin_amdgcn_make_buffer_rsrc(vol + (size_t)k * W * H, 0, (unsigned)((size_t)W * H * 4), 0x00020000);
-    const unsigned vrow = active ? (unsigned)y * 4u : 0x80000000u;  // rows past the image: dropped stores
-    const int colB = H * 4;
+    const size_t sl = ivol_slice_floats(W, H);
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc(vol + (size_t)k * sl, 0, (unsigned)(sl * 4), 0x00020000);
+    const unsigned vrow = active ? (unsigned)y * 16u : 0x80000000u;  // rows past the image: dropped stores
+    const int grpB = H * 16;
     float run = 0.f;
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f;  // the group being collected (the newest value in g3)
     ColDesc dcur = dp[min(lane, W - 1)];
     for (int q0 = 0; q0 < W; q0 += 64) {
         const ColDesc dnext = dp[min(q0 + 64 + lane, W - 1)];
@@ -1127,9 +1172,20 @@ __global__ void __launch_bounds__(256) k_l1_forward(const ColDesc* __restrict__ 
             desc_lane(dcur, j, wc, pc, nc);
             const float cq = column_value<false>(wc, pc, nc, lane, y);
             run = (q0 + j == 0) ? cq : std_min(cq, run + 1);
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(run), rs, vrow, (q0 + j) * colB, 0);
+            g0 = g1; g1 = g2; g2 = g3; g3 = run;
+            if ((j & 3) == 3) {  // q0 is a multiple of 64: the group is complete
+                u32x4 out;
+                out.x = __float_as_uint(g0); out.y = __float_as_uint(g1); out.z = __float_as_uint(g2); out.w = __float_as_uint(g3);
+                __builtin_amdgcn_raw_buffer_store_b128(out, rs, vrow + (unsigned)(((q0 + j) >> 2) * grpB), 0, 0);
+            }
         }
         dcur = dnext;
+    }
+    if (W & 3) {  // the last group is partial: its columns past W are padding and hold 0
+        for (int q = W; q & 3; ++q) { g0 = g1; g1 = g2; g2 = g3; g3 = 0.f; }
+        u32x4 out;
+        out.x = __float_as_uint(g0); out.y = __float_as_uint(g1); out.z = __float_as_uint(g2); out.w = __float_as_uint(g3);
+        __builtin_amdgcn_raw_buffer_store_b128(out, rs, vrow + (unsigned)((W >> 2) * grpB), 0, 0);
     }
 }
 
@@ -1141,37 +1197,57 @@ __global__ void __launch_bounds__(256) k_l1_backward(float* __restrict__ vol, in
     const long k = wid / wps;
     const int y = (int)(wid - k * wps) * 64 + lane;
     if (k * (long)H >= nrows) return;  // wave-uniform
-    // The slice through a buffer descriptor: the column is the scalar offset, the row the lane offset; rows past
-    // the image and columns before 0 get a lane offset of 2^31 (loads 0, drops stores), so no memory operation
+    // The slice through a buffer descriptor: the group of 4 columns is the scalar offset, the row the lane offset; rows
+    // past the image and groups before 0 get a lane offset of 2^31 (loads 0, drops stores), so no memory operation
     // sits behind a branch and two batches of loads stay in flight behind the stores.
-    const auto rs = __builtin_amdgcn_make_buffer_rsrc(vol + (size_t)k * W * H, 0, (unsigned)((size_t)W * H * 4), 0x00020000);
-    const unsigned vrow = y < H ? (unsigned)y * 4u : 0x80000000u;
-    const int colB = H * 4;
-    constexpr int U = 16;
-    float va[U], vb[U];
-    // q runs W-2 .. 0; chunk t covers q = W-2-t*U-j.  Loads never alias earlier stores of the sweep.
-    auto fetch = [&](int t, float (&v)[U]) {
+    const size_t sl = ivol_slice_floats(W, H);
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc(vol + (size_t)k * sl, 0, (unsigned)(sl * 4), 0x00020000);
+    const unsigned vrow = y < H ? (unsigned)y * 16u : 0x80000000u;
+    const int grpB = H * 16;
+    const int W4 = (W + 3) >> 2;
+    // the last group by itself: column W - 1 is the sweep's start (img.col(W-1) stays), padding columns stay 0
+    float run;
+    {
+        u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(rs, vrow, (W4 - 1) * grpB, 0);
+        float v[4] = {__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w)};
+        const int last = (W - 1) & 3;  // uniform
+        run = v[0];
+#pragma unroll
+        for (int cc = 3; cc >= 0; --cc) {
+            if (cc == last) run = v[cc];
+            else if (cc < last) { run = std_min(v[cc], run + 1); v[cc] = run; }
+        }
+        u.x = __float_as_uint(v[0]); u.y = __float_as_uint(v[1]); u.z = __float_as_uint(v[2]); u.w = __float_as_uint(v[3]);
+        __builtin_amdgcn_raw_buffer_store_b128(u, rs, vrow + (unsigned)((W4 - 1) * grpB), 0, 0);
+    }
+    constexpr int U = 4;  // groups per batch
+    u32x4 va[U], vb[U];
+    // groups run W4-2 .. 0; batch t covers G = W4-2-t*U-j.  Loads never alias earlier stores of the sweep.
+    auto fetch = [&](int t, u32x4 (&v)[U]) {
 #pragma unroll
         for (int j = 0; j < U; ++j) {
-            const int q = W - 2 - t * U - j;  // uniform
-            v[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, q >= 0 ? vrow : 0x80000000u, max(q, 0) * colB, 0));
+            const int G = W4 - 2 - t * U - j;  // uniform
+            v[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, G >= 0 ? vrow : 0x80000000u, max(G, 0) * grpB, 0);
         }
     };
-    auto consume = [&](int t, const float (&v)[U], float& run) {
+    auto consume = [&](int t, const u32x4 (&v)[U], float& run) {
 #pragma unroll
         for (int j = 0; j < U; ++j) {
-            const int q = W - 2 - t * U - j;
-            run = std_min(v[j], run + 1);  // past column 0 the value is unused and the store is dropped
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(run), rs, q >= 0 ? vrow : 0x80000000u, max(q, 0) * colB, 0);
+            const int G = W4 - 2 - t * U - j;
+            u32x4 o;  // past group 0 the values are unused and the store is dropped
+            run = std_min(__uint_as_float(v[j].w), run + 1); o.w = __float_as_uint(run);
+            run = std_min(__uint_as_float(v[j].z), run + 1); o.z = __float_as_uint(run);
+            run = std_min(__uint_as_float(v[j].y), run + 1); o.y = __float_as_uint(run);
+            run = std_min(__uint_as_float(v[j].x), run + 1); o.x = __float_as_uint(run);
+            __builtin_amdgcn_raw_buffer_store_b128(o, rs, G >= 0 ? vrow + (unsigned)(G * grpB) : 0x80000000u, 0, 0);
         }
     };
-    float run = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, vrow, (W - 1) * colB, 0));
     fetch(0, va);
     fetch(1, vb);
-    for (int t = 0; t * U < W - 1; t += 2) {
+    for (int t = 0; t * U < W4 - 1; t += 2) {
         consume(t, va, run);
         fetch(t + 2, va);
-        consume(t + 1, vb, run);  // past column 0: dropped stores
+        consume(t + 1, vb, run);  // past group 0: dropped stores
         fetch(t + 3, vb);
     }
 }
@@ -1207,10 +1283,11 @@ __global__ void k_propagate(const float* __restrict__ vol, float* __restrict__ i
     const size_t q = (size_t)blockIdx.x * bd + tid, npix = (size_t)W * H, nq = ivol_slice_floats(W, H);
     const bool ok = q < nq;
     const PropPixel pp = prop_pixel(ok ? q : 0, W, H);
-    const bool in = ok && pp.in_off != 0x80000000u;
+    const bool in_il = (apply_sqrt & 2) != 0;  // the transforms are in the interleaved layout already (segmented L2 sweep)
+    const bool in = ok && (in_il || pp.in_off != 0x80000000u);
     for (int j = 0; j < m; ++j) {
-        float v = in ? vol[(size_t)j * npix + pp.in_off / 4] : 0.f;
-        if (apply_sqrt) v = sqrtf(v);
+        float v = in ? (in_il ? vol[(size_t)j * nq + q] : vol[(size_t)j * npix + pp.in_off / 4]) : 0.f;
+        if (apply_sqrt & 1) v = sqrtf(v);
         S[j * bd + tid] = v;
     }
     for (int s = 0; s < nsteps; ++s) {
@@ -1233,12 +1310,16 @@ __global__ void __launch_bounds__(256) k_propagate_reg(const float* __restrict__
     if (q >= nq) return;
     // One buffer descriptor per slice (scalar registers) + one 32-bit lane byte offset: addresses
     // cost no vector registers, so the M values are the kernel's whole register footprint.
-    const PropPixel pp = prop_pixel(q, W, H);  // slices are < 2^30 pixels
-    const unsigned in_bytes = (unsigned)(npix * 4u), out_bytes = (unsigned)(nq * 4u);
+    PropPixel pp = prop_pixel(q, W, H);  // slices are < 2^30 pixels
+    const bool in_il = (apply_sqrt & 2) != 0;  // the transforms are in the interleaved layout already (segmented L2 sweep)
+    if (in_il) pp.in_off = pp.out_off;
+    apply_sqrt &= 1;
+    const size_t in_slice = in_il ? nq : npix;
+    const unsigned in_bytes = (unsigned)(in_slice * 4u), out_bytes = (unsigned)(nq * 4u);
     float S[M];
 #pragma unroll
     for (int j = 0; j < M; ++j) {
-        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(vol) + (size_t)j * npix, 0, in_bytes, 0x00020000);
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(vol) + (size_t)j * in_slice, 0, in_bytes, 0x00020000);
         S[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, pp.in_off, 0, 0));
     }
     if (apply_sqrt) {
@@ -1308,7 +1389,6 @@ __global__ void k_groups(const IntegralDesc* __restrict__ desc, int* __restrict_
     tab[(size_t)k * stride + G] = word;
 }
 
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float lane_shr1(float v) {  // lane i <- lane i-1 (lane 0 <- 0)
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, true));
 }
@@ -1514,9 +1594,12 @@ constexpr size_t integral_lds_bytes() { return (size_t)2 * (XC + 32 + 4) * 33 * 
 template <int XC>
 __global__ void __launch_bounds__(256) k_integral(const float* __restrict__ src, float* __restrict__ dst, int W, int H,
                                                   const IntegralDesc* __restrict__ desc,
-                                                  const int* __restrict__ tab, int only_mode, int shw) {
+                                                  const int* __restrict__ tab, int only_mode, int shw, int kstride) {
     extern __shared__ float lds_tiles[];
-    const int k = blockIdx.y;
+    // Slices are taken in a strided order (kstride is coprime to the slice count and close to half of it): in index order
+    // all steep slices of one angular range run before the shallow ones, and the two kinds stress different things (LDS
+    // tiles against straight 1 KB streams), so mixing them over the launch overlaps them.
+    const int k = (int)(((long)blockIdx.y * kstride) % (long)gridDim.y);
     const IntegralDesc d = desc[k];
     if (only_mode && d.mode != only_mode) return;  // timing experiment (FDCM_INT_ONLY): one kind of slice only
     if (d.mode == 1) integral_shallow(src, dst, W, H, d, k, tab, shw);
@@ -1568,6 +1651,9 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after) {
     // one-wave-per-chunk kernel, config 3 (1920 chunks) 1.75 against 1.79 ms.  Its scratch is 20 B per pixel against
     // 12 B, so volumes above 2^32 pixels (48 GB of scratch) keep the fused kernel.
     const bool segmented = fm->distance != FDCM_L1 && !env_legacy && (nvox <= (1ull << 32) || env_segments > 0);
+    // the L1 sweeps, the segmented L2 sweep's fill and its redo path write the transforms interleaved (ivol_index);
+    // only the one-wave-per-chunk L2 kernel alone (volumes above 2^32 pixels, FDCM_K2_LEGACY) keeps the y-fastest form
+    fm->vol1_interleaved = segmented || fm->distance == FDCM_L1;
     int R = 64;                            // rows per wave of the one-wave-per-chunk L2 sweep: keep >= 2048 waves in flight
     if (!segmented) {
         while (R > 16 && nchunks * (64 / R) < 2048) R >>= 1;
@@ -1577,8 +1663,13 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after) {
     // segments per row of the segmented sweep: small images need the split most (few rows), but a segment
     // should still hold a few dozen columns
     int S = W >= 128 ? 4 : (W >= 64 ? 2 : 1);
+    // A build that has the GPU to itself and fits it in one go (every block resident at once: the kernel then lasts as
+    // long as its longest block) takes 5 segments, i.e. 320-thread blocks with shorter chains: config 2 0.42 -> 0.38 ms.
+    // With other frames' kernels beside it (pipeline slots) or more blocks than slots (config 3) the four-wave block is
+    // the better one (4 frames in flight: 67 against 59 M matches/s; config 3: 1.03 against 1.35 ms).
+    if (S == 4 && W >= 512 && !fm->shares_gpu && nchunks <= 3L * device_cus(fm->device)) S = 5;
     if (env_segments >= 1 && env_segments <= kSegMax) S = env_segments;
-    const int part_w = (W + kFillParts - 1) / kFillParts;
+    const int part_w = (((W + kFillParts - 1) / kFillParts) + 3) & ~3;  // fill parts start on a group of 4 columns
     fm->coldesc.reserve((size_t)ncols * HW64 * sizeof(ColDesc));
     K2Buf kb{};
     if (fm->distance != FDCM_L1) {
@@ -1681,7 +1772,7 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after) {
             float* sf = (float*)(sv + (size_t)W * nwaves * R);
             float* sz = sf + (size_t)W * nwaves * R;
             const int* gate = nullptr;
-#define FDCM_K2(RR, CC, SS, PP) hipLaunchKernelGGL((k_pass2_l2<RR, CC, SS, PP>), dim3(wblocks), dim3(256), 0, st, d_desc, vol, W, H, HW64, nwaves, sv, sf, sz, gate)
+#define FDCM_K2(RR, CC, SS, PP) hipLaunchKernelGGL((k_pass2_l2<RR, CC, SS, PP>), dim3(wblocks), dim3(256), 0, st, d_desc, vol, W, H, HW64, nwaves, sv, sf, sz, gate, segmented ? 1 : 0)
             if (segmented) {
                 // One launch: the phases' tails overlap between chunks (the three-launch form is kept for measurements:
                 // FDCM_K2_UNFUSED).  More than 4 segments (FDCM_K2_SEGMENTS): 512-thread blocks with an 8-entry ring.
@@ -1809,7 +1900,7 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after) {
         fm->ivol.reserve((size_t)m * nq * sizeof(float));
         float* ivol = fm->ivol.as<float>();
         const unsigned pblocks = (unsigned)((nq + 255) / 256);
-        const int sq = want_sqrt ? 1 : 0;
+        const int sq = (want_sqrt ? 1 : 0) | (fm->vol1_interleaved ? 2 : 0);
         if (m == 30) hipLaunchKernelGGL(k_propagate_reg<30>, dim3(pblocks), dim3(256), 0, st, (const float*)vol, ivol, W, H, d_prop, sq);
         else if (m == 60) hipLaunchKernelGGL(k_propagate_reg<60>, dim3(pblocks), dim3(256), 0, st, (const float*)vol, ivol, W, H, d_prop, sq);
         else if (m == 90) hipLaunchKernelGGL(k_propagate_reg<90>, dim3(pblocks), dim3(256), 0, st, (const float*)vol, ivol, W, H, d_prop, sq);
@@ -1825,7 +1916,8 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after) {
                                d_prop, (int)fm->n_prop, sq);
         }
     } else if (want_sqrt) {
-        hipLaunchKernelGGL(k_sqrt, dim3((unsigned)((nvox + 255) / 256)), dim3(256), 0, st, vol, nvox);
+        const size_t nel = fm->vol1_interleaved ? (size_t)m * ivol_slice_floats(W, H) : nvox;  // (padding elements: harmless)
+        hipLaunchKernelGGL(k_sqrt, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, st, vol, nel);
     }
     FDCM_HIP(hipEventRecord(ev[4], st));
     if (stop_after >= 3) {
@@ -1845,6 +1937,14 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after) {
         const long narrow_blocks = (long)m * ((chains + 59) / 60), cus = device_cus(fm->device);
         const int xc = env_int_xc ? env_int_xc : (narrow_blocks > 64 * cus ? 256 : (narrow_blocks > 12 * cus ? 128 : 64));
         const dim3 igrid((unsigned)((chains + kShOwn - 1) / kShOwn), (unsigned)m);
+        static const int env_int_stride = getenv("FDCM_INT_STRIDE") ? atoi(getenv("FDCM_INT_STRIDE")) : -1;  // measurement: 1 = index order
+        int kstride = 1;
+        if (env_int_stride != 1 && m > 2) {
+            auto gcd = [](int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; };
+            kstride = m / 2 + 1;
+            while (gcd(kstride, m) != 1) ++kstride;
+        }
+        if (env_int_stride > 1) kstride = env_int_stride;
 #define FDCM_INTEGRAL(XC)                                                                                                        \
         do {                                                                                                                     \
             constexpr size_t lds = integral_lds_bytes<XC>();                                                                     \
@@ -1852,7 +1952,7 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after) {
             if (lds > 64 * 1024)                                                                                                 \
                 FDCM_HIP(hipFuncSetAttribute((const void*)k_integral<XC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
             hipLaunchKernelGGL(k_integral<XC>, igrid, dim3(256), lds, st, (const float*)fm->ivol.as<float>(), vol, W, H, d_int,  \
-                               d_tab, env_int_only, shw);                                                                        \
+                               d_tab, env_int_only, shw, kstride);                                                               \
         } while (0)
         if (xc == 256) FDCM_INTEGRAL(256); else if (xc == 128) FDCM_INTEGRAL(128); else FDCM_INTEGRAL(64);
 #undef FDCM_INTEGRAL

@@ -113,6 +113,7 @@ struct fdcm_featuremap {
     long k2_cost_chunks = 0; int k2_cost_w = 0;  // the L2 sweep's per-chunk costs in `stack` are those of a build with this shape
     int off_m = 0, off_steps = 0;  // the group table in `offtab` is valid for this depth and feature width
     bool build_pending = false;  // the last build is queued on `stream` but has not been waited for
+    bool shares_gpu = false;     // a frame slot of a pipeline with several frames in flight: other frames' kernels run beside this handle's
     float build_host_ms = 0.f;   // host time of that call up to its first kernel launch
     // geometry
     int64_t W = 0, H = 0, m = 0;
@@ -124,10 +125,11 @@ struct fdcm_featuremap {
     // `ivol` and writes its sums back into `vol`, interleaved -- which is what the search gathers from.
     fdcm::DevBuf vol;      // max(m*W*H, m*ivol_slice_floats) floats
     fdcm::DevBuf ivol;     // m*ivol_slice_floats floats
-    int vol_stage = 0;     // what the handle holds: 1 = transforms (vol, y-fastest; staged test builds), 2 = propagated
+    bool vol1_interleaved = false;  // the transforms of the last build (stage 1) are in the interleaved layout: segmented L2 sweep
+    int vol_stage = 0;     // what the handle holds: 1 = transforms (vol; staged test builds), 2 = propagated
                            // (ivol, interleaved; staged test builds), 3 = integrated (vol, interleaved): complete
     const float* current() const { return vol_stage == 2 ? ivol.as<float>() : vol.as<float>(); }
-    bool current_interleaved() const { return vol_stage >= 2; }
+    bool current_interleaved() const { return vol_stage >= 2 || (vol_stage == 1 && vol1_interleaved); }
     fdcm::DevBuf bitmap;   // m*W*ceil(H/64) uint64 seed bits along y
     fdcm::DevBuf coldesc;  // m*ceil(H/64)*W column-chunk descriptors (16 B)
     fdcm::DevBuf offtab;   // per slice: one word per group of 4 columns for the shallow sweeps of the line integral (k_groups)

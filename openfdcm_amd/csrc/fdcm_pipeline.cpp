@@ -61,6 +61,7 @@ void run_frame(fdcm_pipeline* p, Slot& s) {
     s.n_out = 0;
     int rc = s.fm ? fdcm_featuremap_rebuild(s.fm, s.scene.data(), s.n_lines)
                   : fdcm_featuremap_build(s.scene.data(), s.n_lines, p->depth, p->coeff, p->padding, p->distance, &s.fm);
+    if (rc == FDCM_OK && s.fm) s.fm->shares_gpu = p->slots.size() > 1;  // (tunes the next builds of this slot)
     if (rc == FDCM_OK) {
         rc = s.out_device
                  ? fdcm_search_device(s.fm, p->templates, s.scene.data(), s.n_lines, p->maxT, p->maxS, p->optimizer,

@@ -182,6 +182,7 @@ void run_slot_frame(fdcm_sharded* s, Shard& sh, FrameSlot& fs) {
         const float* scene = j.scene.data();
         ok(fs.fm ? fdcm_featuremap_rebuild(fs.fm, scene, j.n_scene)
                  : fdcm_featuremap_build(scene, j.n_scene, s->depth, s->coeff, s->padding, s->distance, &fs.fm));
+        fs.fm->shares_gpu = s->n_slots > 1;  // (tunes the next builds of this slot)
         int64_t cap = 0;
         ok(fdcm_search_capacity(sh.tset, j.n_scene, j.maxT, j.maxS, &cap));
         FDCM_HIP(hipSetDevice(sh.device));

@@ -18,7 +18,7 @@ for row in csv.DictReader(open(sys.argv[1])):
     acc[k][row["Counter_Name"]] += float(row["Counter_Value"])
     n[(k, row["Counter_Name"])] += 1
 for k in acc:
-    if any(t in k for t in ("k_env", "k_addend", "k_fill")):
+    if any(t in k for t in ("k_env", "k_addend", "k_fill", "k_sweep", "k_integral", "k_propagate")):
         print(k, {c: round(v / n[(k, c)]) for c, v in acc[k].items()})
 PY
 done

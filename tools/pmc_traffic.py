@@ -2,10 +2,17 @@
 """Turn two rocprofv3 --pmc runs (FETCH_SIZE and WRITE_SIZE, separate passes as MI355X_MICROARCH.md
 prescribes) of `python3 bench.py` into profiles/<name>.json: HBM bytes per launch and kernel.
 
-Units and gfx950 correction (MI355X_MICROARCH.md, section HBM): both counters are in KiB;
-FETCH_SIZE reports exactly half of the bytes of a wide coalesced streaming read, so it is doubled
-(`fetch_corrected`); WRITE_SIZE is exact.  For the gather-dominated k_search the doubling is not
-calibrated and the raw value is kept beside it.
+Units and gfx950 correction (MI355X_MICROARCH.md, section HBM): both counters are in KiB; WRITE_SIZE is exact.
+FETCH_SIZE = memory-side read requests x 64 B, and a request is 64 B or 128 B: calibrated on this GPU with
+tools/fetch_calib.hip (profiles/r03_fetch_calib.json) --
+  * consecutive addresses, 4 B or 16 B per lane (>= 128 B contiguous per wave operation): 128-B requests, the
+    counter reads exactly 1/2 of the bytes -> x2 (the guide's rule);
+  * 4-byte gathers that touch one 64-B sector of a 128-B line: 64-B requests, the counter is exact -> x1;
+  * 4-byte gathers that touch both sectors of a 128-B line in one wave operation: one 128-B request -> x2.
+There is no counter that separates the two request sizes, so every kernel gets a pattern class: "stream" kernels
+(whole-unit loads of >= 128 contiguous bytes per wave operation) are doubled; for "gather" / "mixed" kernels the truth
+lies between the raw value (all requests 64 B) and twice it (all 128 B), both are reported and `fetch_corrected_bytes`
+is the upper bound.
 
 usage: pmc_traffic.py <fetch_dir> <write_dir> <out.json> [command line that was profiled]
 """
@@ -28,12 +35,17 @@ def per_kernel(d, counter):
 def main():
     fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
     out = {}
+    # access pattern of each kernel's HBM reads (see the module docstring)
+    patterns = {"k_search": "gather", "k_evaluate": "gather", "k_sweep": "mixed", "k_env": "mixed", "k_addend": "mixed",
+                "k_pass2_l2": "mixed", "k_topk": "mixed"}
     for k in sorted(set(fetch) | set(write)):
         if not k.startswith("fdcm::"):
             continue
         fr, wr = fetch.get(k, 0.0) * 1024, write.get(k, 0.0) * 1024
-        out[k] = {"fetch_raw_bytes": fr, "fetch_corrected_bytes": 2 * fr, "write_bytes": wr,
-                  "hbm_bytes_per_launch": 2 * fr + wr}
+        pat = next((v for n, v in patterns.items() if n in k), "stream")
+        out[k] = {"read_pattern": pat, "fetch_raw_bytes": fr, "fetch_lower_bytes": fr if pat != "stream" else 2 * fr,
+                  "fetch_corrected_bytes": 2 * fr, "write_bytes": wr, "hbm_bytes_per_launch": 2 * fr + wr,
+                  "hbm_bytes_per_launch_lower": (fr if pat != "stream" else 2 * fr) + wr}
     import hashlib
     import os
     so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "openfdcm_amd", "libfdcm_hip.so")

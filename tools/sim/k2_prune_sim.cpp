@@ -1,0 +1,199 @@
+// k2_prune_sim.cpp -- CPU statistics for "prune, run, verify" (diagnostic, not product code):
+//   1. per row, strong points = minima of b_u = f_u + u^2 over blocks of B seeded columns; their lower convex hull is
+//      an upper bound of the true one (the lower envelope of the parabolas = the lower hull of the points (u, b_u));
+//   2. columns clearly above that coarse hull are pruned (they cannot be envelope vertices in exact arithmetic);
+//   3. the reference's float pass runs on the surviving columns only -> final stack V;
+//   4. every other column g, between the final neighbours v_i < g < v_{i+1}, is verified to be without effect in the
+//      reference's float run:  (A) s(g, v_i) > z(v_i);  (B) s(v_{i+1}, g) <= min over the gap of s(., v_i);  columns
+//      behind the last vertex: (A) and min s(., v_last) >= W - 1.
+//   usage: k2_prune_sim <seed file> [B=8]
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+struct Ent { int v; float f, z; };
+static inline float isect(float fq, int q, float fv, int v) {
+    const float qf = (float)q, vf = (float)v;
+    return ((fq + qf * qf) - fv - vf * vf) / (2 * qf - 2 * vf);
+}
+static inline void step(std::vector<Ent>& st, int q, float fq) {
+    while (true) {
+        const int k = (int)st.size() - 1;
+        const float s = isect(fq, q, st[k].f, st[k].v);
+        if (s > st[k].z || k == 0) { st.push_back(Ent{q, fq, s}); break; }
+        st.pop_back();
+    }
+}
+int main(int argc, char** argv) {
+    FILE* fp = fopen(argv[1], "rb");
+    int32_t hdr[3];
+    if (!fp || fread(hdr, 4, 3, fp) != 3) return 1;
+    const int m = hdr[0], W = hdr[1], H = hdr[2];
+    const int B = argc > 2 ? atoi(argv[2]) : 8;
+    const int uniform = argc > 3 ? atoi(argv[3]) : 0;  // 1: one prune decision per (chunk, column) from the value range over the chunk's rows
+    std::vector<uint8_t> seed((size_t)W * H);
+    long rows = 0, rows_fail = 0, rows_diff = 0, chunks = 0, chunks_fail = 0;
+    long cols_total = 0, surv_rows = 0, surv_wave = 0;
+    double path_now = 0, path_new = 0, pmax_now = 0, pmax_new = 0;
+    for (int k = 0; k < m; ++k) {
+        if (fread(seed.data(), 1, seed.size(), fp) != seed.size()) return 2;
+        std::vector<int> cols;
+        for (int x = 0; x < W; ++x) { bool any = false; for (int y = 0; y < H && !any; ++y) any = seed[(size_t)x * H + y]; if (any) cols.push_back(x); }
+        const int n = (int)cols.size();
+        if (n < 2) continue;
+        std::vector<float> f((size_t)n * H);
+        for (int j = 0; j < n; ++j) {
+            const uint8_t* c = &seed[(size_t)cols[j] * H];
+            int last = -(1 << 20);
+            for (int y = 0; y < H; ++y) { if (c[y]) last = y; f[(size_t)j * H + y] = (float)(y - last); }
+            int nxt = 1 << 20;
+            for (int y = H - 1; y >= 0; --y) { if (c[y]) nxt = y; float d = std::min(f[(size_t)j * H + y], (float)(nxt - y)); f[(size_t)j * H + y] = d * d; }
+        }
+        for (int c0 = 0; c0 < H; c0 += 64, ++chunks) {
+            const int c1 = std::min(H, c0 + 64);
+            std::vector<int> keep_cnt((size_t)n, 0);
+            bool chunk_fail = false;
+            std::vector<char> ukeep((size_t)n, 1);
+            if (uniform) {
+                std::vector<double> lo((size_t)n), hi((size_t)n);
+                for (int j = 0; j < n; ++j) {
+                    double l = 1e300, h = -1;
+                    for (int y = c0; y < c1; ++y) { l = std::min<double>(l, f[(size_t)j * H + y]); h = std::max<double>(h, f[(size_t)j * H + y]); }
+                    lo[j] = l + (double)cols[j] * cols[j]; hi[j] = h + (double)cols[j] * cols[j];
+                }
+                std::vector<int> strong;
+                strong.push_back(0);
+                for (int j0 = 0; j0 < n; j0 += B) {
+                    int best = j0;
+                    for (int j = j0; j < std::min(n, j0 + B); ++j) if (hi[j] < hi[best]) best = j;
+                    if (best != strong.back()) strong.push_back(best);
+                }
+                if (strong.back() != n - 1) strong.push_back(n - 1);
+                std::sort(strong.begin(), strong.end());
+                strong.erase(std::unique(strong.begin(), strong.end()), strong.end());
+                std::vector<int> hull;
+                for (int j : strong) {
+                    while (hull.size() >= 2) {
+                        const int a = hull[hull.size() - 2], b = hull.back();
+                        const double cross = (hi[b] - hi[a]) * (cols[j] - cols[a]) - (hi[j] - hi[a]) * (cols[b] - cols[a]);
+                        if (cross >= 0) hull.pop_back(); else break;
+                    }
+                    hull.push_back(j);
+                }
+                size_t hp = 0;
+                for (int j = 0; j < n; ++j) {
+                    while (hp + 1 < hull.size() && hull[hp + 1] <= j) ++hp;
+                    if (hull[hp] == j || hp + 1 >= hull.size()) continue;
+                    const int a = hull[hp], c = hull[hp + 1];
+                    const double chord = hi[a] + (hi[c] - hi[a]) * (cols[j] - cols[a]) / (double)(cols[c] - cols[a]);
+                    ukeep[j] = !(lo[j] > chord + 1e-4 * std::fabs(chord) + 0.5);
+                }
+                ukeep[0] = 1;
+            }
+            for (int y = c0; y < c1; ++y, ++rows) {
+                auto F = [&](int j) { return f[(size_t)j * H + y]; };
+                auto Bv = [&](int j) { return (double)F(j) + (double)cols[j] * cols[j]; };
+                // strong points
+                std::vector<int> strong;
+                strong.push_back(0);
+                for (int j0 = 0; j0 < n; j0 += B) {
+                    int best = j0;
+                    for (int j = j0; j < std::min(n, j0 + B); ++j) if (Bv(j) < Bv(best)) best = j;
+                    if (best != strong.back()) strong.push_back(best);
+                }
+                if (strong.back() != n - 1) strong.push_back(n - 1);
+                std::sort(strong.begin(), strong.end());
+                strong.erase(std::unique(strong.begin(), strong.end()), strong.end());
+                // lower hull of the strong points
+                std::vector<int> hull;
+                for (int j : strong) {
+                    while (hull.size() >= 2) {
+                        const int a = hull[hull.size() - 2], b = hull.back();
+                        // b above or on segment a-j ?
+                        const double cross = (Bv(b) - Bv(a)) * (cols[j] - cols[a]) - (Bv(j) - Bv(a)) * (cols[b] - cols[a]);
+                        if (cross >= 0) hull.pop_back(); else break;
+                    }
+                    hull.push_back(j);
+                }
+                // prune
+                std::vector<char> keep((size_t)n, 0);
+                size_t hp = 0;
+                for (int j = 0; j < n; ++j) {
+                    while (hp + 1 < hull.size() && hull[hp + 1] <= j) ++hp;
+                    if (hull[hp] == j || hp + 1 >= hull.size()) { keep[j] = 1; continue; }
+                    const int a = hull[hp], c = hull[hp + 1];
+                    const double chord = Bv(a) + (Bv(c) - Bv(a)) * (cols[j] - cols[a]) / (double)(cols[c] - cols[a]);
+                    keep[j] = !(Bv(j) > chord + 1e-4 * std::fabs(chord) + 0.5);
+                }
+                keep[0] = 1;
+                if (uniform == 1) for (int j = 0; j < n; ++j) keep[j] = ukeep[j];
+                if (uniform == 2) {
+                    // block minima, then for a column of block k: a = lowest point of blocks < k, c = lowest point of blocks > k
+                    const int nb = (n + B - 1) / B;
+                    std::vector<int> bmin((size_t)nb), pre((size_t)nb), suf((size_t)nb);
+                    for (int k2 = 0; k2 < nb; ++k2) { int best = k2 * B; for (int j = k2 * B; j < std::min(n, k2 * B + B); ++j) if (Bv(j) < Bv(best)) best = j; bmin[k2] = best; }
+                    pre[0] = bmin[0];
+                    for (int k2 = 1; k2 < nb; ++k2) pre[k2] = Bv(bmin[k2]) < Bv(pre[k2 - 1]) ? bmin[k2] : pre[k2 - 1];
+                    suf[nb - 1] = bmin[nb - 1];
+                    for (int k2 = nb - 2; k2 >= 0; --k2) suf[k2] = Bv(bmin[k2]) <= Bv(suf[k2 + 1]) ? bmin[k2] : suf[k2 + 1];
+                    for (int j = 0; j < n; ++j) {
+                        const int k2 = j / B;
+                        keep[j] = 1;
+                        if (k2 == 0 || k2 == nb - 1) continue;
+                        const int a = pre[k2 - 1], c = suf[k2 + 1];
+                        const double chord = Bv(a) + (Bv(c) - Bv(a)) * (cols[j] - cols[a]) / (double)(cols[c] - cols[a]);
+                        keep[j] = !(Bv(j) > chord + 1e-4 * std::fabs(chord) + 0.5);
+                    }
+                    keep[0] = 1;
+                }
+                // float run on the survivors
+                std::vector<Ent> st;
+                st.push_back(Ent{cols[0], F(0), -INFINITY});
+                for (int j = 1; j < n; ++j) if (keep[j]) step(st, cols[j], F(j));
+                // the true run (sanity)
+                std::vector<Ent> tr;
+                tr.push_back(Ent{cols[0], F(0), -INFINITY});
+                for (int j = 1; j < n; ++j) step(tr, cols[j], F(j));
+                // verification of every non-final column
+                bool ok = true;
+                size_t i = 0;
+                float mA = INFINITY, MB = -INFINITY;
+                for (int j = 1; j < n && ok; ++j) {
+                    if (i + 1 < st.size() && st[i + 1].v == cols[j]) {
+                        if (mA != INFINITY) ok = ok && (mA > st[i].z) && (MB <= mA);
+                        ++i; mA = INFINITY; MB = -INFINITY;
+                        continue;
+                    }
+                    mA = std::min(mA, isect(F(j), cols[j], st[i].f, st[i].v));
+                    if (i + 1 < st.size()) MB = std::max(MB, isect(st[i + 1].f, st[i + 1].v, F(j), cols[j]));
+                }
+                if (ok && mA != INFINITY) ok = (mA > st[i].z) && (i + 1 < st.size() ? false : mA >= (float)(W - 1));
+                // does the survivors' stack own the same pixels as the true one?
+                auto owners = [&](const std::vector<Ent>& s) {
+                    std::vector<std::pair<int, int>> o;  // (first pixel, column)
+                    size_t kk = 0;
+                    int lastv = -1;
+                    for (int q = 0; q < W; ++q) { while (kk + 1 < s.size() && s[kk + 1].z < (float)q) ++kk; if (s[kk].v != lastv) { o.push_back({q, s[kk].v}); lastv = s[kk].v; } }
+                    return o;
+                };
+                const bool same_owners = owners(st) == owners(tr);
+                if (!ok) { ++rows_fail; chunk_fail = true; }
+                if (ok && !same_owners) ++rows_diff;   // must never happen: verified but different
+                for (int j = 0; j < n; ++j) { keep_cnt[j] += keep[j]; surv_rows += keep[j]; }
+            }
+            chunks_fail += chunk_fail;
+            long wave_keep = 0;
+            for (int j = 0; j < n; ++j) wave_keep += keep_cnt[j] > 0;
+            surv_wave += wave_keep; cols_total += n;
+            const double now = n, nw = wave_keep + (n - wave_keep) * 0.2 + n * 0.15;  // survivors full cost, pruned 0.2, + prune/verify passes ~0.15 each column
+            path_now += now; path_new += nw; pmax_now = std::max(pmax_now, now); pmax_new = std::max(pmax_new, nw);
+        }
+        fprintf(stderr, "slice %d (%d seeded): rows failing so far %ld of %ld\n", k, n, rows_fail, rows);
+    }
+    printf("B=%d: survivors row-level %.1f %%, wave-level (kept by any of the 64 rows) %.1f %%; rows failing verification %ld of %ld (chunks %ld of %ld); verified-but-different rows %ld\n",
+           B, 100.0 * surv_rows / (64.0 * cols_total), 100.0 * surv_wave / cols_total, rows_fail, rows, chunks_fail, chunks, rows_diff);
+    printf("  chain per chunk (column equivalents, S=1): now avg %.1f max %.0f -> new avg %.1f max %.1f\n", path_now / chunks, pmax_now, path_new / chunks, pmax_new);
+    return 0;
+}
