@@ -1672,6 +1672,8 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after) {
     const int part_w = (((W + kFillParts - 1) / kFillParts) + 3) & ~3;  // fill parts start on a group of 4 columns
     fm->coldesc.reserve((size_t)ncols * HW64 * sizeof(ColDesc));
     K2Buf kb{};
+    bool proxy_order = false;
+    int* order_dst = nullptr;
     if (fm->distance != FDCM_L1) {
         // scratch of the L2 sweeps: envelope entries (W + kSegMax + 2 slots per row, 12 B), owner list (W + 2
         // entries per row, 8 B), per-segment and per-row records, chunk flags
@@ -1697,8 +1699,12 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after) {
         static const int env_lpt = getenv("FDCM_K2_LPT") ? atoi(getenv("FDCM_K2_LPT")) : -1;
         const bool want_order = env_lpt >= 0 ? env_lpt != 0 : nchunks > 3L * device_cus(fm->device);
         const bool have_cost = want_order && segmented && fm->k2_cost_chunks == nchunks && fm->k2_cost_w == W && stack_before == fm->stack.p;
+        // without history (a handle's first build, a change of size): the host's proxy per chunk (make_build_plan), which
+        // arrives with the plan blob; k_order is queued behind that copy below
+        proxy_order = want_order && segmented && !have_cost && plan.chunk_cost.size() == (size_t)nchunks;
         if (have_cost) hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, st, (const int*)(sb + o_cost), (int)nchunks, (int*)(sb + o_ord));
-        kb.order = have_cost ? (const int*)(sb + o_ord) : nullptr;
+        kb.order = (have_cost || proxy_order) ? (const int*)(sb + o_ord) : nullptr;
+        order_dst = (int*)(sb + o_ord);
         kb.cost = (int*)(sb + o_cost);
         fm->k2_cost_chunks = segmented ? nchunks : 0; fm->k2_cost_w = W;
         kb.ent = (EnvEntry*)(sb + o_ent); kb.own = (OwnEntry*)(sb + o_own);
@@ -1715,7 +1721,8 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after) {
     fm->off_prop = align16(plan.raster.size() * sizeof(RasterLine));
     fm->off_integral = fm->off_prop + align16(plan.prop.size() * sizeof(PropStep));
     fm->off_keys = fm->off_integral + align16(plan.integral.size() * sizeof(IntegralDesc));
-    const size_t blob = fm->off_keys + align16(plan.keys.size() * sizeof(float));
+    fm->off_cost = fm->off_keys + align16(plan.keys.size() * sizeof(float));
+    const size_t blob = fm->off_cost + (proxy_order ? align16(plan.chunk_cost.size() * sizeof(int32_t)) : 0);
     fm->stage.reserve(blob);
     fm->plan.reserve(blob);
     char* hs = (char*)fm->stage.p;
@@ -1723,7 +1730,10 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after) {
     std::memcpy(hs + fm->off_prop, plan.prop.data(), plan.prop.size() * sizeof(PropStep));
     std::memcpy(hs + fm->off_integral, plan.integral.data(), plan.integral.size() * sizeof(IntegralDesc));
     std::memcpy(hs + fm->off_keys, plan.keys.data(), plan.keys.size() * sizeof(float));
+    if (proxy_order) std::memcpy(hs + fm->off_cost, plan.chunk_cost.data(), plan.chunk_cost.size() * sizeof(int32_t));
     FDCM_HIP(hipMemcpyAsync(fm->plan.p, hs, blob, hipMemcpyHostToDevice, st));
+    if (proxy_order)
+        hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, st, (const int*)((const char*)fm->plan.p + fm->off_cost), (int)nchunks, order_dst);
     fm->n_raster = (int64_t)plan.raster.size();
     fm->n_prop = (int64_t)plan.prop.size();
     const char* dp = (const char*)fm->plan.p;

@@ -66,6 +66,7 @@ struct BuildPlan {
     std::vector<RasterLine> raster;
     std::vector<PropStep> prop;
     std::vector<IntegralDesc> integral;
+    std::vector<int32_t> chunk_cost;  // per (slice, 64-row chunk): a proxy of the L2 sweep's time, for the launch order of a first build
 };
 
 // Host side of buildCpuFeaturemap (dt3cpu.h:174-198 + the scalar parts of :227-231).
@@ -136,7 +137,7 @@ struct fdcm_featuremap {
     fdcm::DevBuf stack;    // K2 scratch: per row a (v, f, z) stack of W entries
     fdcm::DevBuf plan;     // RasterLine[] | PropStep[] | IntegralDesc[] | keys[]
     fdcm::PinnedBuf stage; // host staging for the plan
-    size_t off_raster = 0, off_prop = 0, off_integral = 0, off_keys = 0;
+    size_t off_raster = 0, off_prop = 0, off_integral = 0, off_keys = 0, off_cost = 0;
     int64_t n_raster = 0, n_prop = 0;
     // search workspaces
     fdcm::DevBuf s_scene;   // scene lines + sorted lengths + sorted idx
