@@ -27,7 +27,7 @@ stats bench_config2p_frames1 python3 $R/bench.py --cpu-sample 0 --frames 1 --sin
 pmc config2p python3 $R/bench.py --frames 1 --steps 5 --warmup 2 --cpu-sample 0 --single-frames 0
 # bench.py reports `roofline.traffic` from profiles/*pmc_traffic*config2p*.json when that file was measured on the running
 # library: put the fresh one there (this copy of the repository is scratch) before the judged bench lines are taken
-cp $OUT/pmc_traffic_config2p.json $R/profiles/${2:-r02}_pmc_traffic_config2p.json
+cp $OUT/pmc_traffic_config2p.json $R/profiles/${2:-r03}_pmc_traffic_config2p.json
 python3 $R/bench.py > $OUT/bench.json 2> $OUT/bench.err
 python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_cmd.json 2>> $OUT/bench.err
 for cfg in 3 5; do
@@ -35,5 +35,13 @@ for cfg in 3 5; do
   stats config$cfg python3 $R/tools/run_config.py --config $cfg --check none --reps 7 --search --templates 200
   pmc config$cfg python3 $R/tools/run_config.py --config $cfg --check none --reps 3
 done
+# round 3: first build / same scene / changed scene (the L2 sweep's launch order comes from the handle's history),
+# the FETCH_SIZE calibration, the sharded engine with frames in flight, the multi-scene and strong-scaling bench lines
+python3 $R/tools/run_config.py --config 3 --check none --reps 9 --perturb > $OUT/run_config3_history.json 2>> $OUT/bench.err
+python3 $R/tools/run_config.py --config 2 --check none --reps 9 --perturb > $OUT/run_config2_history.json 2>> $OUT/bench.err
+bash $R/tools/fetch_calib.sh > /dev/null 2>&1 && cp $R/gpurun_out/fetch_calib.json $OUT/fetch_calib.json
+python3 $R/tools/sharded_bench.py --frames 4 --steps 200 2>> $OUT/bench.err | tail -1 > $OUT/sharded_bench.json
+python3 $R/bench.py --scenes 4 --steps 200 --warmup 10 > $OUT/bench_4scenes.json 2>> $OUT/bench.err
+python3 $R/bench.py --scaling strong --steps 200 --warmup 10 --cpu-sample 0 > $OUT/bench_strong_n1.json 2>> $OUT/bench.err
 cut -c1-300 $OUT/bench.json
 for f in $OUT/*_kernel_stats.csv; do echo $f; head -4 $f | cut -c1-110; done
