@@ -55,6 +55,20 @@ int main(void) {
             printf("  #%lld score %.6f  t = (%.3f, %.3f)\n", (long long)i, best[i].score, best[i].transform[2], best[i].transform[5]);
         fdcm_matches_free(best);
     }
+    /* the feature-map seam (featuremap.h:27-52): what an optimiser that lives outside the library calls */
+    {
+        const float align_vec[2] = {1.f, 0.f};
+        float lim[2] = {0, 0};
+        const float moved[6] = {0, 0, 3, 0, -2, 1};  /* three translations of the template */
+        const int64_t toff[] = {0, 3};
+        float score[3] = {0, 0, 0};
+        if (fdcm_featuremap_minmax_translation(fm, tmpl, 3, align_vec, lim) != FDCM_OK ||
+            fdcm_featuremap_evaluate(fm, tmpl, offsets, 1, moved, toff, score) != FDCM_OK) {
+            printf("%s\n", fdcm_last_error());
+            return 2;
+        }
+        printf("seam: multipliers of (1, 0) in [%.0f, %.0f]; scores %.4f %.4f %.4f\n", lim[0], lim[1], score[0], score[1], score[2]);
+    }
     fdcm_matches_free(out);
     fdcm_templates_free(ts);
     fdcm_featuremap_free(fm);

@@ -55,6 +55,22 @@ def test_argument_errors_are_reported_not_thrown(capi):
     assert rc == -1 and b"distance" in lib.fdcm_last_error()
     rc = lib.fdcm_search_capacity(None, 1, 1, 1, None)
     assert rc == -1
+    # round 3's entry points: the feature-map seam and the sharded engine's frames in flight
+    one = np.zeros(2, dtype=np.float32)
+    off = np.array([0, 1], dtype=np.int64)
+    i64p = C.POINTER(C.c_int64)
+    assert lib.fdcm_featuremap_minmax_translation(None, capi.fptr(scene), 1, capi.fptr(one), capi.fptr(one)) == -1
+    assert b"featuremap" in lib.fdcm_last_error()
+    assert lib.fdcm_featuremap_minmax_translation(None, capi.fptr(scene), -1, capi.fptr(one), capi.fptr(one)) == -1
+    assert lib.fdcm_featuremap_evaluate(None, capi.fptr(scene), off.ctypes.data_as(i64p), 1, capi.fptr(one),
+                                        off.ctypes.data_as(i64p), capi.fptr(one)) == -1
+    t = C.c_int64()
+    assert lib.fdcm_sharded_submit(None, capi.fptr(scene), 1, 4, 4, 1, 10, C.byref(t)) == -1
+    assert lib.fdcm_sharded_wait(None, 0, C.byref(out), C.byref(t)) == -1
+    assert lib.fdcm_sharded_set_frames_in_flight(None, 2) == -1
+    d = C.c_int(-7)
+    assert lib.fdcm_get_device(C.byref(d)) == 0 and d.value == 0  # the thread's default
+    assert lib.fdcm_get_device(None) == -1
 
 
 def test_lineio_roundtrip_and_assets(tmp_path):
@@ -96,4 +112,4 @@ def test_c_example_on_device(capi, tmp_path):
     exe = _build_c_example(tmp_path)
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "raw matches" in out.stdout and "#0 score" in out.stdout, out.stdout
+    assert "raw matches" in out.stdout and "#0 score" in out.stdout and "seam: multipliers of (1, 0) in [" in out.stdout, out.stdout
