@@ -75,7 +75,9 @@ __global__ void __launch_bounds__(256) k_evaluate(const float* __restrict__ vol,
         }
     }
     inside = inside && __shfl_xor((int)inside, 32) != 0;
-    const float s = pair_score(vol, L, n, offx, offy, ivol_slice_floats(W, H), (size_t)H, h, act && inside);
+    // (64-bit addresses: the seam serves volumes of any size and is not the hot path; L[5 i + 4] holds the bin)
+    const VolRef V = make_volref(vol, ivol_slice_floats(W, H), 0, false);
+    const float s = pair_score<false>(V, L, n, offx, offy, (unsigned)H, h, act && inside);
     if (act && h == 0) scores[e.first + slot] = inside ? s : f_nan();
 }
 

@@ -76,20 +76,21 @@ struct SearchParams {
 static constexpr int kWavesPerBlock = 4;
 
 struct OptState {
+    VolRef V;        // the integrated volume
     const float* L;  // aligned lines of the candidate (LDS)
     float* sc;       // score window (LDS): [0, WIN) positive, [WIN, 2 WIN) negative, [2 WIN] translation 0
     int n_t, lane, B, WIN;
     bool batch_rule;
     bool reset_back;  // IndulgentOptimize: the negative direction compares against the initial score again
-    size_t W, H;  // W: floats per slice of the interleaved volume (ivol_slice_floats)
+    unsigned H;
     float tx, ty, savx, savy;
     int lim_p, lim_n;  // multiplier limits: 32 bits are enough, see k_search
 };
 
 // Score multipliers k_from, k_from + dir, ... (cnt of them) into sc[dst ..]; with_zero additionally
 // scores translation (0,0) into sc[2 WIN].  32 translations per gather round.
-__device__ __forceinline__ void score_range(const float* __restrict__ vol, const OptState& o, int dir, int k_from,
-                                            int cnt, int dst, bool with_zero) {
+template <bool BUF32>
+__device__ __forceinline__ void score_range(const OptState& o, int dir, int k_from, int cnt, int dst, bool with_zero) {
     const int h = o.lane >> 5, slot = o.lane & 31;  // neighbouring lanes = neighbouring translations
     const int total = cnt + (with_zero ? 1 : 0);
     for (int s0 = 0; s0 < total; s0 += 32) {
@@ -98,7 +99,7 @@ __device__ __forceinline__ void score_range(const float* __restrict__ vol, const
         const int k = idx < 0 ? 0 : k_from + dir * idx;
         // translation = float(k) * scaled_align_vec (:58/:81); Point2{0,0} for the initial score (:36)
         const float trx = idx < 0 ? 0.f : (float)k * o.savx, try_ = idx < 0 ? 0.f : (float)k * o.savy;
-        const float s = pair_score(vol, o.L, o.n_t, o.tx + trx, o.ty + try_, o.W, o.H, h, act);
+        const float s = pair_score<BUF32>(o.V, o.L, o.n_t, o.tx + trx, o.ty + try_, o.H, h, act);
         if (act && h == 0) o.sc[idx < 0 ? 2 * o.WIN : dst + idx] = s;
     }
 }
@@ -108,8 +109,8 @@ __device__ __forceinline__ void score_range(const float* __restrict__ vol, const
 // the rule.  IndulgentOptimize walks like DefaultOptimize (a passed-through score is scored again at the
 // same multiplier until the allowance is used up, then the walk breaks) but starts the negative direction
 // from the initial score again.
-__device__ __forceinline__ void optimise(const float* __restrict__ vol, const OptState& o, float& best, int& best_k,
-                                         int& n_eval) {
+template <bool BUF32>
+__device__ __forceinline__ void optimise(const OptState& o, float& best, int& best_k, int& n_eval) {
     const int WIN = o.WIN, B = o.B;
     const int h = o.lane >> 5, slot = o.lane & 31;  // neighbouring lanes = neighbouring translations
     // ---- round 1: translation 0 and the first WIN multipliers of both directions
@@ -122,11 +123,11 @@ __device__ __forceinline__ void optimise(const float* __restrict__ vol, const Op
         const bool act = slot == 0 || is_p || is_n;
         const int k = is_p ? 1 + idx : (is_n ? -1 - (idx - have_p) : 0);
         const float trx = slot == 0 ? 0.f : (float)k * o.savx, try_ = slot == 0 ? 0.f : (float)k * o.savy;
-        const float s = pair_score(vol, o.L, o.n_t, o.tx + trx, o.ty + try_, o.W, o.H, h, act);
+        const float s = pair_score<BUF32>(o.V, o.L, o.n_t, o.tx + trx, o.ty + try_, o.H, h, act);
         if (act && h == 0) o.sc[slot == 0 ? 2 * WIN : (is_p ? idx : WIN + (idx - have_p))] = s;
     } else {
-        score_range(vol, o, +1, 1, have_p, 0, true);
-        score_range(vol, o, -1, -1, have_n, WIN, false);
+        score_range<BUF32>(o, +1, 1, have_p, 0, true);
+        score_range<BUF32>(o, -1, -1, have_n, WIN, false);
     }
     const float init = o.sc[2 * WIN];
     n_eval += 1;
@@ -150,7 +151,7 @@ __device__ __forceinline__ void optimise(const float* __restrict__ vol, const Op
                     win0 = k0 + dir * c0;
                     const int left = dir > 0 ? (lim - win0 + 1) : (win0 - lim + 1);
                     have = min(WIN, left);
-                    score_range(vol, o, dir, win0, have, off, false);
+                    score_range<BUF32>(o, dir, win0, have, off, false);
                     rel = 0;
                 }
                 const int take = min(nb - c0, have - rel);
@@ -332,6 +333,7 @@ __global__ void __launch_bounds__(1024) k_wl_scatter(const SearchParams P, long 
 #ifndef FDCM_SEARCH_WPE
 #define FDCM_SEARCH_WPE 4
 #endif
+template <bool BUF32>
 __global__ void __launch_bounds__(256, FDCM_SEARCH_WPE) k_search(const SearchParams P) {
     extern __shared__ float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -361,6 +363,7 @@ __global__ void __launch_bounds__(256, FDCM_SEARCH_WPE) k_search(const SearchPar
     float* sc = L + 5 * P.lds_lines;
     for (int i = lane; i < P.m; i += 64) s_keys[i] = P.keys[i];
     const long long cand = P.cand_offsets[t] + local;
+    const VolRef V = make_volref(P.vol, ivol_slice_floats(P.W, P.H), P.m, BUF32);
 
     // ---- which candidate: sorted template line j, window slot wi, alignment flip
     const int flip = local & 1, pair = local >> 1;
@@ -388,7 +391,7 @@ __global__ void __launch_bounds__(256, FDCM_SEARCH_WPE) k_search(const SearchPar
             bin = closest_orientation(s_keys, P.m, angle);  // dt3cpu.cpp:144-148
         }
         float* d = L + 5 * i;
-        d[0] = x1; d[1] = y1; d[2] = x2; d[3] = y2; d[4] = __int_as_float(bin);
+        d[0] = x1; d[1] = y1; d[2] = x2; d[3] = y2; d[4] = line_slice_word(V, bin);
         mnx = std_min(mnx, std_min(x1, x2)); mxx = std_max(mxx, std_max(x1, x2));
         mny = std_min(mny, std_min(y1, y2)); mxy = std_max(mxy, std_max(y1, y2));
     }
@@ -413,7 +416,7 @@ __global__ void __launch_bounds__(256, FDCM_SEARCH_WPE) k_search(const SearchPar
     int best_k = 0, n_eval = 0;
     if (valid) {
         OptState o;
-        o.L = L; o.sc = sc; o.n_t = n_t; o.W = ivol_slice_floats(P.W, P.H); o.H = (size_t)P.H; o.tx = P.tx; o.ty = P.ty;
+        o.V = V; o.L = L; o.sc = sc; o.n_t = n_t; o.H = (unsigned)P.H; o.tx = P.tx; o.ty = P.ty;
         o.savx = savx; o.savy = savy; o.lane = lane;
         o.B = P.optimizer == FDCM_BATCH_OPTIMIZE ? P.batch : 1; o.WIN = P.win; o.batch_rule = P.optimizer == FDCM_BATCH_OPTIMIZE;
         o.reset_back = P.optimizer == FDCM_INDULGENT_OPTIMIZE;
@@ -424,7 +427,7 @@ __global__ void __launch_bounds__(256, FDCM_SEARCH_WPE) k_search(const SearchPar
         const long long lp = (long long)max_mul, ln = (long long)min_mul;
         o.lim_p = (int)std::min<long long>(std::max<long long>(lp, -(1ll << 30)), 1ll << 30);
         o.lim_n = (int)std::min<long long>(std::max<long long>(ln, -(1ll << 30)), 1ll << 30);
-        optimise(P.vol, o, best, best_k, n_eval);
+        optimise<BUF32>(o, best, best_k, n_eval);
     }
     if (lane == 0) {
         fdcm_match r;
@@ -637,8 +640,12 @@ void run_search(fdcm_featuremap* fm, const fdcm_templates* t, const float* scene
     const size_t lds_floats = (size_t)kWavesPerBlock * ((size_t)P.m + 5 * (size_t)P.lds_lines + 2 * P.win + 1);
     const size_t lds = lds_floats * sizeof(float);
     if (lds > 160 * 1024) throw std::string("scene/template too large for the search kernel's LDS staging");
+    // volumes below 4 GB (every BASELINE config but 5) are addressed through one buffer descriptor with 32-bit offsets
+    static const bool env_flat = getenv("FDCM_SEARCH_FLAT") != nullptr;  // measurement: 64-bit flat addresses always
+    const bool buf32 = !env_flat && (size_t)fm->m * ivol_slice_floats(fm->W, fm->H) * sizeof(float) < ((size_t)1 << 32);
     if (lds > 64 * 1024)
-        FDCM_HIP(hipFuncSetAttribute((const void*)k_search, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        FDCM_HIP(hipFuncSetAttribute(buf32 ? (const void*)k_search<true> : (const void*)k_search<false>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t* ev = fm->timing.ev;
     FDCM_HIP(hipEventRecord(ev[6], st));
     hipLaunchKernelGGL(k_pairs, dim3((unsigned)(((size_t)t->T * maxT + 255) / 256)), dim3(256), 0, st, P);
@@ -714,7 +721,8 @@ void run_search(fdcm_featuremap* fm, const fdcm_templates* t, const float* scene
         FDCM_HIP(hipMemcpyAsync(fm->s_bins.p, hb, (size_t)ncand * stride * sizeof(unsigned short), hipMemcpyHostToDevice, st));
         P.host_bins = fm->s_bins.as<unsigned short>();
     }
-    hipLaunchKernelGGL(k_search, dim3((unsigned)P.nblocks), dim3(256), lds, st, P);
+    if (buf32) hipLaunchKernelGGL(k_search<true>, dim3((unsigned)P.nblocks), dim3(256), lds, st, P);
+    else hipLaunchKernelGGL(k_search<false>, dim3((unsigned)P.nblocks), dim3(256), lds, st, P);
     fdcm_match* dst = out_device;
     if (!dst) {
         // host output: one extra record behind the candidates' capacity carries the counters, so that the
