@@ -37,6 +37,7 @@ int main(int argc, char** argv) {
     long rows = 0, rows_fail = 0, rows_diff = 0, chunks = 0, chunks_fail = 0;
     long cols_total = 0, surv_rows = 0, surv_wave = 0;
     double path_now = 0, path_new = 0, pmax_now = 0, pmax_new = 0;
+    long seg_now_sum = 0, seg_new_sum = 0, seg_now_max = 0, seg_new_max = 0;
     for (int k = 0; k < m; ++k) {
         if (fread(seed.data(), 1, seed.size(), fp) != seed.size()) return 2;
         std::vector<int> cols;
@@ -56,6 +57,7 @@ int main(int argc, char** argv) {
             std::vector<int> keep_cnt((size_t)n, 0);
             bool chunk_fail = false;
             std::vector<char> ukeep((size_t)n, 1);
+            std::vector<std::vector<int>> seg_all(16, std::vector<int>((size_t)n, 0)), seg_keep(16, std::vector<int>((size_t)n, 0));
             if (uniform) {
                 std::vector<double> lo((size_t)n), hi((size_t)n);
                 for (int j = 0; j < n; ++j) {
@@ -129,6 +131,32 @@ int main(int argc, char** argv) {
                 }
                 keep[0] = 1;
                 if (uniform == 1) for (int j = 0; j < n; ++j) keep[j] = ukeep[j];
+                if (uniform == 3) {
+                    // the true run gives the final vertices; primary junctions = owners of the j / S quantile pixels of the
+                    // seeded columns (what k_sweep's phase A finds), plus the owner of the row's last pixel
+                    std::vector<Ent> tr0;
+                    tr0.push_back(Ent{cols[0], F(0), -INFINITY});
+                    for (int j = 1; j < n; ++j) step(tr0, cols[j], F(j));
+                    const int S = B;  // (the second argument is the segment count in this mode)
+                    std::vector<int> jun;
+                    jun.push_back(0);
+                    auto owner_of = [&](int xq) { int own = tr0[0].v; for (auto& e : tr0) if (e.z < (float)xq) own = e.v; return (int)(std::lower_bound(cols.begin(), cols.end(), own) - cols.begin()); };
+                    for (int w = 1; w < S; ++w) { const int j = owner_of(cols[(int)((long)n * w / S)]); if (j > jun.back()) jun.push_back(j); }
+                    { const int j = owner_of(W - 1); if (j > jun.back()) jun.push_back(j); }
+                    for (int j = 0; j < n; ++j) keep[j] = 1;
+                    for (size_t p = 0; p + 1 < jun.size(); ++p) {
+                        const int a = jun[p], c = jun[p + 1];
+                        for (int j = a + 1; j < c; ++j) {
+                            const double chord = Bv(a) + (Bv(c) - Bv(a)) * (cols[j] - cols[a]) / (double)(cols[c] - cols[a]);
+                            keep[j] = !(Bv(j) > chord + 1e-4 * std::fabs(chord) + 0.5);
+                        }
+                    }
+                    keep[0] = 1;
+                    for (size_t p = 0; p < jun.size(); ++p) {  // segment p = columns (jun[p], jun[p + 1]] (the last one: to the end)
+                        const int a = jun[p], c = p + 1 < jun.size() ? jun[p + 1] : n - 1;
+                        for (int j = a + 1; j <= c; ++j) { seg_all[p][j] = 1; if (keep[j]) seg_keep[p][j] = 1; }
+                    }
+                }
                 if (uniform == 2) {
                     // block minima, then for a column of block k: a = lowest point of blocks < k, c = lowest point of blocks > k
                     const int nb = (n + B - 1) / B;
@@ -183,6 +211,11 @@ int main(int argc, char** argv) {
                 if (ok && !same_owners) ++rows_diff;   // must never happen: verified but different
                 for (int j = 0; j < n; ++j) { keep_cnt[j] += keep[j]; surv_rows += keep[j]; }
             }
+            if (uniform == 3) {
+                long wa = 0, wk = 0;
+                for (int p = 0; p < 16; ++p) { long a = 0, kq = 0; for (int j = 0; j < n; ++j) { a += seg_all[p][j]; kq += seg_keep[p][j]; } wa = std::max(wa, a); wk = std::max(wk, kq); }
+                seg_now_sum += wa; seg_new_sum += wk; seg_now_max = std::max(seg_now_max, wa); seg_new_max = std::max(seg_new_max, wk);
+            }
             chunks_fail += chunk_fail;
             long wave_keep = 0;
             for (int j = 0; j < n; ++j) wave_keep += keep_cnt[j] > 0;
@@ -195,5 +228,6 @@ int main(int argc, char** argv) {
     printf("B=%d: survivors row-level %.1f %%, wave-level (kept by any of the 64 rows) %.1f %%; rows failing verification %ld of %ld (chunks %ld of %ld); verified-but-different rows %ld\n",
            B, 100.0 * surv_rows / (64.0 * cols_total), 100.0 * surv_wave / cols_total, rows_fail, rows, chunks_fail, chunks, rows_diff);
     printf("  chain per chunk (column equivalents, S=1): now avg %.1f max %.0f -> new avg %.1f max %.1f\n", path_now / chunks, pmax_now, path_new / chunks, pmax_new);
+    if (uniform == 3) printf("  longest wave-level segment per chunk (columns): now avg %.1f max %ld -> processed after chord pruning avg %.1f max %ld\n", (double)seg_now_sum / chunks, seg_now_max, (double)seg_new_sum / chunks, seg_new_max);
     return 0;
 }
