@@ -187,6 +187,11 @@ int fdcm_blocks_to_host(const void* blocks_device, int32_t n_blocks, int64_t cap
  * single shard also sends its records to itself through RCCL: a test hook for one-GPU machines).  Every entry point
  * leaves the caller's current device (the library's and HIP's) as it found it. */
 #define FDCM_SHARDED_ALWAYS_COLLECTIVE 1
+/* Test hook for one-GPU machines: `devices` may name a device more than once.  Shards that live on the first shard's
+ * device hand their records over with device copies (RCCL cannot put one device into a communicator twice), everything
+ * else -- ranges, one worker per shard and frame slot, offsets into the gathered array, the top-k merge -- is the
+ * multi-device code. */
+#define FDCM_SHARDED_ALLOW_SAME_DEVICE 2
 typedef struct fdcm_sharded fdcm_sharded;
 int fdcm_sharded_create(const int* devices, int n_devices, const float* tmpl_lines, const int64_t* offsets /* n_templates+1 */,
                         int64_t n_templates, int64_t depth, float dt3_coeff, float padding, int distance, int flags,

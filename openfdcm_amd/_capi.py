@@ -15,6 +15,7 @@ L2, L2_SQUARED, L1 = 0, 1, 2
 DEFAULT_OPTIMIZE, BATCH_OPTIMIZE, INDULGENT_OPTIMIZE = 0, 1, 2
 DEFAULT_PENALTY, EXPONENTIAL_PENALTY = 0, 1
 SHARDED_ALWAYS_COLLECTIVE = 1
+SHARDED_ALLOW_SAME_DEVICE = 2
 
 MATCH_DTYPE = np.dtype([("tmpl_idx", "<i4"), ("score", "<f4"), ("transform", "<f4", (6,))])
 assert MATCH_DTYPE.itemsize == 32

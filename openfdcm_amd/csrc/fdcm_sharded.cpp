@@ -132,6 +132,7 @@ struct fdcm_sharded {
     std::vector<Shard> shards;
     std::vector<ncclComm_t> comms;
     bool always_collective = false;
+    bool same_device_ok = false;   // FDCM_SHARDED_ALLOW_SAME_DEVICE (test hook)
     int64_t depth = 0;
     float coeff = 0.f, padding = 0.f;
     int distance = 0;
@@ -312,9 +313,11 @@ int64_t gather_to_first(fdcm_sharded* s, size_t si) {
     FDCM_HIP(hipSetDevice(root.device));
     s->gathered.reserve(std::max<size_t>(32, (size_t)total * sizeof(fdcm_match)));
     fdcm_match* dst = s->gathered.as<fdcm_match>();
-    const bool single = s->shards.size() == 1 && !s->always_collective;
-    if (single) {  // nothing to exchange: the records already are on the first (only) device
-        if (total) FDCM_HIP(hipMemcpyAsync(dst, root.slots[si]->send_from, (size_t)total * sizeof(fdcm_match), hipMemcpyDeviceToDevice, root.stream));
+    if (s->comms.empty()) {  // nothing to exchange between devices: every shard's records already are on the first device
+        for (size_t i = 0; i < s->shards.size(); ++i) {
+            const FrameSlot& fs = *s->shards[i].slots[si];
+            if (fs.n) FDCM_HIP(hipMemcpyAsync(dst + off[i], fs.send_from, (size_t)fs.n * sizeof(fdcm_match), hipMemcpyDeviceToDevice, root.stream));
+        }
         FDCM_HIP(hipStreamSynchronize(root.stream));
         return total;
     }
@@ -427,13 +430,15 @@ int fdcm_sharded_create(const int* devices, int n_devices, const float* tmpl_lin
         s = new fdcm_sharded();
         s->depth = depth; s->coeff = dt3_coeff; s->padding = padding; s->distance = distance;
         s->always_collective = (flags & FDCM_SHARDED_ALWAYS_COLLECTIVE) != 0;
+        s->same_device_ok = (flags & FDCM_SHARDED_ALLOW_SAME_DEVICE) != 0;
+        if (s->same_device_ok && s->always_collective) throw std::string("ALLOW_SAME_DEVICE and ALWAYS_COLLECTIVE exclude each other");
         s->shards.resize((size_t)n_devices);
         std::vector<int> devs((size_t)n_devices);
         for (int i = 0; i < n_devices; ++i) {
             devs[i] = devices ? devices[i] : i;
             if (devs[i] < 0 || devs[i] >= have) throw std::string("device ") + std::to_string(devs[i]) + " does not exist";
             for (int j = 0; j < i; ++j)
-                if (devs[j] == devs[i]) throw std::string("a device is listed twice");
+                if (devs[j] == devs[i] && !s->same_device_ok) throw std::string("a device is listed twice");
         }
         for (int i = 0; i < n_devices; ++i) {
             Shard& sh = s->shards[(size_t)i];
@@ -449,7 +454,10 @@ int fdcm_sharded_create(const int* devices, int n_devices, const float* tmpl_lin
             if (r != FDCM_OK) throw std::string(fdcm_last_error());
             FDCM_HIP(hipStreamCreateWithFlags(&sh.stream, hipStreamNonBlocking));
         }
-        if (n_devices > 1 || s->always_collective) {
+        bool all_on_root = true;
+        for (int i = 1; i < n_devices; ++i) all_on_root = all_on_root && devs[i] == devs[0];
+        if ((n_devices > 1 && !all_on_root) || s->always_collective) {
+            if (s->same_device_ok) throw std::string("ALLOW_SAME_DEVICE: every shard must be on the first shard's device");
             Rccl& R = rccl();
             if (!R.error.empty()) throw R.error;
             s->comms.assign((size_t)n_devices, nullptr);

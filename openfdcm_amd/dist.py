@@ -216,6 +216,12 @@ class ShardedPipeline:
                              max_tmpl_lines=max_tmpl_lines, max_scene_lines=max_scene_lines, optimizer=optimizer,
                              batch_size=batch_size, tmpl_index_base=searcher.begin, slots=slots)
         cap = searcher.tset.capacity(n_scene_lines, max_tmpl_lines, max_scene_lines)
+        if searcher.world > 1:
+            # the per-frame gather moves equal-sized blocks: every rank uses the largest shard's capacity (shards differ
+            # when the template count does not divide by the ranks, or when templates have different line counts)
+            c = torch.tensor([cap], dtype=torch.int64, device=searcher.device)
+            dist.all_reduce(c, op=dist.ReduceOp.MAX, group=group)
+            cap = int(c.item())
         return cls(pipe, searcher.world, searcher.device, cap, slots, group, gather)
 
     def submit(self, scene_records):

@@ -281,7 +281,7 @@ class ShardedEngine:
     return for the whole template list."""
 
     def __init__(self, templates, devices=None, n_devices=None, depth=30, coeff=5.0, padding=2.2, distance=capi.L2,
-                 always_collective=False):
+                 always_collective=False, allow_same_device=False):
         flat, offsets = capi.pack_templates(templates)
         if devices is not None:
             n_devices = len(devices)
@@ -292,7 +292,8 @@ class ShardedEngine:
         h = C.c_void_p()
         capi.check(capi.lib().fdcm_sharded_create(dev, n_devices, capi.fptr(flat) if flat.size else None,
                                                   offsets.ctypes.data_as(C.POINTER(C.c_int64)), len(templates), depth, coeff,
-                                                  padding, distance, capi.SHARDED_ALWAYS_COLLECTIVE if always_collective else 0,
+                                                  padding, distance, (capi.SHARDED_ALWAYS_COLLECTIVE if always_collective else 0) |
+                                                  (capi.SHARDED_ALLOW_SAME_DEVICE if allow_same_device else 0),
                                                   C.byref(h)))
         self._h, self.n_devices, self.n_templates = h, n_devices, len(templates)
 

@@ -696,6 +696,44 @@ def test_sharded_engine_leaves_the_callers_device_alone(amd):
     assert current() == before
 
 
+def test_sharded_engine_several_shards_on_one_device(amd):
+    """The multi-shard logic of fdcm_sharded_* on a one-GPU box (FDCM_SHARDED_ALLOW_SAME_DEVICE: devices = [0, 0, 0]):
+    contiguous ranges, a worker per shard and frame slot, per-shard offsets into the gathered array, uneven shards and
+    shards without templates (fewer templates than shards), frames in flight, the top-k merge across shards -- everything
+    of the multi-device path except RCCL's transport between devices, which the one-device RCCL test covers."""
+    from openfdcm_amd import synthetic, _capi
+    from openfdcm_amd.engine import DeviceFeatureMap, DeviceTemplates, ShardedEngine, search_raw, topk
+    S = 256
+    scenes = [synthetic.scene(S, 50, 61), synthetic.scene(S, 35, 62), synthetic.scene(S, 44, 63)]
+    for T, shards in ((17, 3), (2, 3), (1, 4), (9, 2)):
+        tmpls = synthetic.templates(T, 12, S, 70 + T)
+        eng = ShardedEngine(tmpls, devices=[0] * shards, depth=16, coeff=5.0, padding=1.0, distance=O.L2, allow_same_device=True)
+        assert eng.info()["shard_begin"] == [T * i // shards for i in range(shards + 1)]
+        eng.set_frames_in_flight(2)
+        tset = DeviceTemplates(tmpls)
+        fm = DeviceFeatureMap.build(scenes[0], depth=16, coeff=5.0, padding=1.0, distance=O.L2)
+        want, want_top = [], []
+        for sc in scenes:
+            fm.rebuild(sc)
+            want.append(np.array(search_raw(fm, tset, sc, 4, 4, _capi.BATCH_OPTIMIZE, 10), copy=True))
+            want_top.append({k: np.array(topk(fm, tset, k, 1, 1.5), copy=True) for k in (1, 7, len(want[-1]) + 3)})
+        pend = []
+        for i, sc in enumerate(scenes * 2):
+            if len(pend) == 2:
+                t, j = pend.pop(0)
+                assert eng.wait(t).tobytes() == want[j].tobytes(), (T, shards, t)
+            pend.append((eng.submit(sc, 4, 4, _capi.BATCH_OPTIMIZE, 10), i % len(scenes)))
+        for t, j in pend:
+            assert eng.wait(t).tobytes() == want[j].tobytes(), (T, shards, t)
+        for j, sc in enumerate(scenes):
+            for k, w in want_top[j].items():
+                assert eng.search_topk(sc, 4, 4, k, penalty=1, tau=1.5).tobytes() == w.tobytes(), (T, shards, j, k)
+        assert eng.info()["collectives"] == 0
+        eng.close()
+    with pytest.raises(_capi.FdcmError, match="twice"):
+        ShardedEngine(synthetic.templates(4, 5, 128, 3), devices=[0, 0])
+
+
 def test_sharded_engine_several_devices(amd):
     """fdcm_sharded_* with more than one device -- ncclCommInitAll over several devices, workers per device,
     cross-device send/recv into the gathered array at per-shard offsets, the top-k merge across shards, uneven and empty

@@ -40,7 +40,7 @@ done
 python3 $R/tools/run_config.py --config 3 --check none --reps 9 --perturb > $OUT/run_config3_history.json 2>> $OUT/bench.err
 python3 $R/tools/run_config.py --config 2 --check none --reps 9 --perturb > $OUT/run_config2_history.json 2>> $OUT/bench.err
 bash $R/tools/fetch_calib.sh > /dev/null 2>&1 && cp $R/gpurun_out/fetch_calib.json $OUT/fetch_calib.json
-python3 $R/tools/sharded_bench.py --frames 4 --steps 200 2>> $OUT/bench.err | tail -1 > $OUT/sharded_bench.json
+python3 $R/tools/sharded_bench.py --frames 4 --steps 200 2>> $OUT/bench.err | grep '^{' | tail -1 > $OUT/sharded_bench.json
 python3 $R/bench.py --scenes 4 --steps 200 --warmup 10 > $OUT/bench_4scenes.json 2>> $OUT/bench.err
 python3 $R/bench.py --scaling strong --steps 200 --warmup 10 --cpu-sample 0 > $OUT/bench_strong_n1.json 2>> $OUT/bench.err
 cut -c1-300 $OUT/bench.json
