@@ -1944,7 +1944,9 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after) {
             fm->off_m = m; fm->off_steps = W;
         }
         static const int env_int_only = getenv("FDCM_INT_ONLY") ? atoi(getenv("FDCM_INT_ONLY")) : 0;  // timing experiment
-        const int shw = (long)m * ((chains + kShOwn - 1) / kShOwn) > 8192 ? 4 : 1;  // working waves per workgroup of a shallow slice
+        static const int env_int_shw = getenv("FDCM_INT_SHW") ? atoi(getenv("FDCM_INT_SHW")) : 0;  // measurement: 1, 2 or 4
+        int shw = (long)m * ((chains + kShOwn - 1) / kShOwn) > 8192 ? 4 : 1;  // working waves per workgroup of a shallow slice
+        if (env_int_shw == 1 || env_int_shw == 2 || env_int_shw == 4) shw = env_int_shw;
         // steep slices: 60 own chains per block while the launch is small, 124 / 252 once such blocks would outnumber
         // what the GPU holds several times over (fewer columns read twice; see integral_steep)
         static const int env_int_xc = getenv("FDCM_INT_XC") ? atoi(getenv("FDCM_INT_XC")) : 0;  // measurement: 64 / 128 / 256
