@@ -32,7 +32,8 @@ int main(int argc, char** argv) {
     if (!fp || fread(hdr, 4, 3, fp) != 3) return 1;
     const int m = hdr[0], W = hdr[1], H = hdr[2];
     const int B = argc > 2 ? atoi(argv[2]) : 8;
-    const int uniform = argc > 3 ? atoi(argv[3]) : 0;  // 1: one prune decision per (chunk, column) from the value range over the chunk's rows
+    const int uniform = argc > 3 ? atoi(argv[3]) : 0;
+    const int statS = argc > 4 ? atoi(argv[4]) : 5;  // primary segments per row for the longest-segment statistic (modes other than 3)  // 1: one prune decision per (chunk, column) from the value range over the chunk's rows
     std::vector<uint8_t> seed((size_t)W * H);
     long rows = 0, rows_fail = 0, rows_diff = 0, chunks = 0, chunks_fail = 0;
     long cols_total = 0, surv_rows = 0, surv_wave = 0;
@@ -176,6 +177,19 @@ int main(int argc, char** argv) {
                     }
                     keep[0] = 1;
                 }
+                if (uniform != 3) {  // longest-segment statistic with primary junctions like k_sweep's (owners of quantile pixels)
+                    std::vector<Ent> tr0;
+                    tr0.push_back(Ent{cols[0], F(0), -INFINITY});
+                    for (int j = 1; j < n; ++j) step(tr0, cols[j], F(j));
+                    std::vector<int> jun;
+                    jun.push_back(0);
+                    auto owner_of = [&](int xq) { int own = tr0[0].v; for (auto& e : tr0) if (e.z < (float)xq) own = e.v; return (int)(std::lower_bound(cols.begin(), cols.end(), own) - cols.begin()); };
+                    for (int w = 1; w < statS; ++w) { const int j = owner_of(cols[(int)((long)n * w / statS)]); if (j > jun.back()) jun.push_back(j); }
+                    for (size_t p = 0; p < jun.size(); ++p) {
+                        const int a = jun[p], c = p + 1 < jun.size() ? jun[p + 1] : n - 1;
+                        for (int j = a + 1; j <= c; ++j) { seg_all[p][j] = 1; if (keep[j]) seg_keep[p][j] = 1; }
+                    }
+                }
                 // float run on the survivors
                 std::vector<Ent> st;
                 st.push_back(Ent{cols[0], F(0), -INFINITY});
@@ -211,7 +225,7 @@ int main(int argc, char** argv) {
                 if (ok && !same_owners) ++rows_diff;   // must never happen: verified but different
                 for (int j = 0; j < n; ++j) { keep_cnt[j] += keep[j]; surv_rows += keep[j]; }
             }
-            if (uniform == 3) {
+            {
                 long wa = 0, wk = 0;
                 for (int p = 0; p < 16; ++p) { long a = 0, kq = 0; for (int j = 0; j < n; ++j) { a += seg_all[p][j]; kq += seg_keep[p][j]; } wa = std::max(wa, a); wk = std::max(wk, kq); }
                 seg_now_sum += wa; seg_new_sum += wk; seg_now_max = std::max(seg_now_max, wa); seg_new_max = std::max(seg_new_max, wk);
@@ -228,6 +242,6 @@ int main(int argc, char** argv) {
     printf("B=%d: survivors row-level %.1f %%, wave-level (kept by any of the 64 rows) %.1f %%; rows failing verification %ld of %ld (chunks %ld of %ld); verified-but-different rows %ld\n",
            B, 100.0 * surv_rows / (64.0 * cols_total), 100.0 * surv_wave / cols_total, rows_fail, rows, chunks_fail, chunks, rows_diff);
     printf("  chain per chunk (column equivalents, S=1): now avg %.1f max %.0f -> new avg %.1f max %.1f\n", path_now / chunks, pmax_now, path_new / chunks, pmax_new);
-    if (uniform == 3) printf("  longest wave-level segment per chunk (columns): now avg %.1f max %ld -> processed after chord pruning avg %.1f max %ld\n", (double)seg_now_sum / chunks, seg_now_max, (double)seg_new_sum / chunks, seg_new_max);
+    printf("  longest wave-level segment per chunk (columns): now avg %.1f max %ld -> processed after chord pruning avg %.1f max %ld\n", (double)seg_now_sum / chunks, seg_now_max, (double)seg_new_sum / chunks, seg_new_max);
     return 0;
 }

@@ -5,10 +5,12 @@ from openfdcm_amd import synthetic
 from openfdcm_amd.engine import DeviceFeatureMap
 from oracle import oracle as O
 """Which build stage first differs from the oracle: sampled slices of a BASELINE config after stage 1 (transforms), 2
-(propagation), 3 (line integral); diagnostic (found the 16-byte-store hazard at config 5).  usage: stage_parity.py <config> [depth]"""
+(propagation), 3 (line integral); diagnostic (found the 16-byte-store hazard at config 5).  usage: stage_parity.py <config> [depth] [distance 0|1|2]"""
 name = sys.argv[1]
 cfg = dict(synthetic.CONFIGS[name])
 depth = int(sys.argv[2]) if len(sys.argv) > 2 else cfg["depth"]
+if len(sys.argv) > 3:
+    cfg["distance"] = int(sys.argv[3])
 scene = synthetic.scene(cfg["S"], cfg["scene_lines"], 1)
 for stop in (1, 2, 3):
     dev = DeviceFeatureMap.build(scene, depth=depth, coeff=5.0, padding=1.0, distance=cfg["distance"], stop_after=stop)
