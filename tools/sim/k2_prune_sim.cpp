@@ -39,6 +39,9 @@ int main(int argc, char** argv) {
     long cols_total = 0, surv_rows = 0, surv_wave = 0;
     double path_now = 0, path_new = 0, pmax_now = 0, pmax_new = 0;
     long seg_now_sum = 0, seg_new_sum = 0, seg_now_max = 0, seg_new_max = 0;
+    long la_dead = 0, la_mat = 0, la_unsound = 0, la_wave_proc = 0, la_wave_mat = 0;
+    long b_fail1 = 0, b_fail2 = 0, b_fail3 = 0, b_fail23 = 0, b_runs = 0;
+    long inloop_rows_fail = 0, inloop_failA = 0, inloop_failB = 0, inloop_unsound = 0, inloop_wave_keep = 0;
     for (int k = 0; k < m; ++k) {
         if (fread(seed.data(), 1, seed.size(), fp) != seed.size()) return 2;
         std::vector<int> cols;
@@ -55,7 +58,7 @@ int main(int argc, char** argv) {
         }
         for (int c0 = 0; c0 < H; c0 += 64, ++chunks) {
             const int c1 = std::min(H, c0 + 64);
-            std::vector<int> keep_cnt((size_t)n, 0);
+            std::vector<int> keep_cnt((size_t)n, 0), keep2_cnt((size_t)n, 0), la_mat_col((size_t)n, 0), la_proc_col((size_t)n, 0);
             bool chunk_fail = false;
             std::vector<char> ukeep((size_t)n, 1);
             std::vector<std::vector<int>> seg_all(16, std::vector<int>((size_t)n, 0)), seg_keep(16, std::vector<int>((size_t)n, 0));
@@ -122,6 +125,8 @@ int main(int argc, char** argv) {
                 }
                 // prune
                 std::vector<char> keep((size_t)n, 0);
+                std::vector<double> chordv((size_t)n, 0.0);
+                std::vector<int> edge_id((size_t)n, -1);
                 size_t hp = 0;
                 for (int j = 0; j < n; ++j) {
                     while (hp + 1 < hull.size() && hull[hp + 1] <= j) ++hp;
@@ -129,6 +134,7 @@ int main(int argc, char** argv) {
                     const int a = hull[hp], c = hull[hp + 1];
                     const double chord = Bv(a) + (Bv(c) - Bv(a)) * (cols[j] - cols[a]) / (double)(cols[c] - cols[a]);
                     keep[j] = !(Bv(j) > chord + 1e-4 * std::fabs(chord) + 0.5);
+                    chordv[j] = chord; edge_id[j] = (int)hp;
                 }
                 keep[0] = 1;
                 if (uniform == 1) for (int j = 0; j < n; ++j) keep[j] = ukeep[j];
@@ -190,6 +196,84 @@ int main(int argc, char** argv) {
                         for (int j = a + 1; j <= c; ++j) { seg_all[p][j] = 1; if (keep[j]) seg_keep[p][j] = 1; }
                     }
                 }
+                {   // the in-loop rule: a column above the chord is skipped only if it would not pop the top at that time
+                    // (else it is processed like any other); a run of skipped columns is certified (B) by the next
+                    // processed column
+                    std::vector<Ent> st2;
+                    st2.push_back(Ent{cols[0], F(0), -INFINITY});
+                    bool okrow = true;
+                    float mA = INFINITY;
+                    std::vector<int> run;
+                    for (int j = 1; j < n; ++j) {
+                        bool skip = !keep[j];
+                        if (skip) {
+                            const Ent& t = st2.back();
+                            const float sg = isect(F(j), cols[j], t.f, t.v);
+                            if (st2.size() > 1 && !(sg > t.z)) { skip = false; ++inloop_failA; }  // processed after all
+                            else { mA = std::min(mA, sg); run.push_back(j); }
+                        }
+                        if (!skip) {
+                            if (!run.empty() && uniform == 0) {
+                                // the GPU's bounds for max_g s(r, g): chord based, chord + minimal excess, minimal b
+                                const int gf = run.front(), gl = run.back();
+                                double dmin = 1e300, bmn = 1e300;
+                                for (int g : run) { dmin = std::min(dmin, Bv(g) - chordv[g]); bmn = std::min(bmn, Bv(g)); }
+                                auto lin = [&](int g) { return chordv[gf] + (chordv[gl] - chordv[gf]) * (gl == gf ? 0.0 : (double)(cols[g] - cols[gf]) / (cols[gl] - cols[gf])); };
+                                const double br = Bv(j);
+                                const double phi1 = std::max((br - lin(gf)) / (2.0 * (cols[j] - cols[gf])), (br - lin(gl)) / (2.0 * (cols[j] - cols[gl])));
+                                const double phi2 = std::max((br - lin(gf) - dmin) / (2.0 * (cols[j] - cols[gf])), (br - lin(gl) - dmin) / (2.0 * (cols[j] - cols[gl])));
+                                const double num = br - bmn;
+                                const double phi3 = num >= 0 ? num / (2.0 * (cols[j] - cols[gl])) : num / (2.0 * (cols[j] - cols[gf]));
+                                if (!(phi1 <= mA)) ++b_fail1;
+                                if (!(phi2 <= mA)) ++b_fail2;
+                                if (!(phi3 <= mA)) ++b_fail3;
+                                if (!(std::min(phi2, phi3) <= mA)) ++b_fail23;
+                                ++b_runs;
+                            }
+                            for (int g : run) if (!(isect(F(j), cols[j], F(g), cols[g]) <= mA)) { okrow = false; ++inloop_failB; }
+                            run.clear(); mA = INFINITY;
+                            step(st2, cols[j], F(j));
+                            keep2_cnt[j] += 1;
+                        }
+                    }
+                    if (!run.empty()) okrow = false;
+                    inloop_rows_fail += !okrow;
+                    // sanity: same final stack as the true run
+                    std::vector<Ent> tr2;
+                    tr2.push_back(Ent{cols[0], F(0), -INFINITY});
+                    for (int j = 1; j < n; ++j) step(tr2, cols[j], F(j));
+                    bool same = tr2.size() == st2.size();
+                    for (size_t i = 0; same && i < tr2.size(); ++i) same = tr2[i].v == st2[i].v && (i == 0 || tr2[i].z == st2[i].z);
+                    if (okrow && !same) ++inloop_unsound;
+                }
+                if (uniform == 0) {   // lookahead rule: a candidate (above the chord, does not pop the top) is deferred; the next seeded
+                    // column either pops it at once (s(next, g) <= s(g, t): it vanishes) or it is pushed after all
+                    std::vector<Ent> st3;
+                    st3.push_back(Ent{cols[0], F(0), -INFINITY});
+                    int pend = -1; float pend_s = 0.f;
+                    for (int j = 1; j < n; ++j) {
+                        if (pend >= 0) {
+                            const bool dead = isect(F(j), cols[j], F(pend), cols[pend]) <= pend_s;
+                            if (dead) { ++la_dead; }
+                            else { step(st3, cols[pend], F(pend)); ++la_mat; la_mat_col[j] += 1; }
+                            pend = -1;
+                        }
+                        bool defer = false;
+                        if (!keep[j] && j + 1 < n) {
+                            const Ent& t = st3.back();
+                            const float sg = isect(F(j), cols[j], t.f, t.v);
+                            if (st3.size() == 1 || sg > t.z) { defer = true; pend = j; pend_s = sg; }
+                        }
+                        if (!defer) { step(st3, cols[j], F(j)); la_proc_col[j] += 1; }
+                    }
+                    if (pend >= 0) step(st3, cols[pend], F(pend));
+                    std::vector<Ent> tr3;
+                    tr3.push_back(Ent{cols[0], F(0), -INFINITY});
+                    for (int j = 1; j < n; ++j) step(tr3, cols[j], F(j));
+                    bool same = tr3.size() == st3.size();
+                    for (size_t i = 0; same && i < tr3.size(); ++i) same = tr3[i].v == st3[i].v && (i == 0 || tr3[i].z == st3[i].z);
+                    if (!same) ++la_unsound;
+                }
                 // float run on the survivors
                 std::vector<Ent> st;
                 st.push_back(Ent{cols[0], F(0), -INFINITY});
@@ -230,6 +314,7 @@ int main(int argc, char** argv) {
                 for (int p = 0; p < 16; ++p) { long a = 0, kq = 0; for (int j = 0; j < n; ++j) { a += seg_all[p][j]; kq += seg_keep[p][j]; } wa = std::max(wa, a); wk = std::max(wk, kq); }
                 seg_now_sum += wa; seg_new_sum += wk; seg_now_max = std::max(seg_now_max, wa); seg_new_max = std::max(seg_new_max, wk);
             }
+            for (int j = 0; j < n; ++j) { inloop_wave_keep += keep2_cnt[j] > 0; la_wave_proc += la_proc_col[j] > 0; la_wave_mat += la_mat_col[j] > 0; }
             chunks_fail += chunk_fail;
             long wave_keep = 0;
             for (int j = 0; j < n; ++j) wave_keep += keep_cnt[j] > 0;
@@ -242,6 +327,9 @@ int main(int argc, char** argv) {
     printf("B=%d: survivors row-level %.1f %%, wave-level (kept by any of the 64 rows) %.1f %%; rows failing verification %ld of %ld (chunks %ld of %ld); verified-but-different rows %ld\n",
            B, 100.0 * surv_rows / (64.0 * cols_total), 100.0 * surv_wave / cols_total, rows_fail, rows, chunks_fail, chunks, rows_diff);
     printf("  chain per chunk (column equivalents, S=1): now avg %.1f max %.0f -> new avg %.1f max %.1f\n", path_now / chunks, pmax_now, path_new / chunks, pmax_new);
+    printf("  in-loop rule: columns processed after all because they would pop the top %ld; rows failing (B) %ld of %ld (%ld pairs); certified-but-different rows %ld; processed per wave %.1f %%\n", inloop_failA, inloop_rows_fail, rows, inloop_failB, inloop_unsound, 100.0 * inloop_wave_keep / cols_total);
+    printf("  lookahead rule: deferred columns that vanish %.1f %% of all (row, column), pushed after all %.1f %%; per wave: columns processed %.1f %%, columns with a late push %.1f %%; rows differing from the true run %ld\n", 100.0 * la_dead / (64.0 * cols_total), 100.0 * la_mat / (64.0 * cols_total), 100.0 * la_wave_proc / cols_total, 100.0 * la_wave_mat / cols_total, la_unsound);
+    printf("  bounds for (B) over %ld runs: chord %ld fail, chord + minimal excess %ld, minimal b %ld, better of the last two %ld\n", b_runs, b_fail1, b_fail2, b_fail3, b_fail23);
     printf("  longest wave-level segment per chunk (columns): now avg %.1f max %ld -> processed after chord pruning avg %.1f max %ld\n", (double)seg_now_sum / chunks, seg_now_max, (double)seg_new_sum / chunks, seg_new_max);
     return 0;
 }
