@@ -531,16 +531,17 @@ def test_search_many_templates_generic_work_list(amd):
                                             ({"FDCM_K2_LEGACY": "1"}, 40, 14),
                                             ({"FDCM_FORCE_HOST_BINS": "1"}, 40, 15),
                                             ({"FDCM_INT_XC": "256"}, 30, 16),
-                                            ({"FDCM_INT_XC": "128"}, 30, 17)],
+                                            ({"FDCM_INT_XC": "128"}, 30, 17),
+                                            ({"FDCM_SEARCH_FLAT": "1"}, 30, 18)],
                          ids=["default", "8-segments+forced-redo", "3-segments", "one-wave-per-chunk", "host-libm-bins",
-                              "integral-252-chain-blocks", "integral-124-chain-blocks"])
+                              "integral-252-chain-blocks", "integral-124-chain-blocks", "search-with-64-bit-addresses"])
 def test_randomised_cases(amd, env, cases, seed):
     """Random (scene, depth, distance, padding, coefficient, optimiser, template set) cases: volume and match list
     bit for bit (tools/fuzz_parity.py).  The variants force the paths of the L2 sweep that the default sizes do not
     take: eight segments per row with every fifth chunk sent through the redo path (a failed junction check), three
     segments, and the one-wave-per-chunk kernel alone; the orientation bins of the aligned template lines from the host
     libm (the path a host whose atanf differs from the device restatement takes); the wide-block forms of the steep
-    line integral that only large volumes select."""
+    line integral that only large volumes select; the search with 64-bit flat addresses (what volumes of 4 GB and more take)."""
     import os
     import subprocess
     import sys
