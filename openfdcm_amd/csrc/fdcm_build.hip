@@ -23,6 +23,7 @@
 #include <cstring>
 
 #include "fdcm_internal.h"
+#include "fdcm_quotient.h"
 
 namespace fdcm {
 
@@ -742,7 +743,10 @@ __device__ __forceinline__ void env_phase(const ColDesc* __restrict__ desc, int 
                         if (DBG) ++n_iter;
                         // s = ((f[q] + q^2) - f[v] - v^2) / (2q - 2v), left to right in float (imgproc.h:111)
                         const float N = (hq - tf) - tv2;
-                        s = N / (twoq - tvx2);
+                        // = N / (2q - 2v) bit for bit in 4 instructions for 11 (fdcm_quotient.h), except that N = -inf (the
+                        // unseeded bottom column of the first segment) comes out as NaN instead of -inf: "not greater than
+                        // tz" either way, and the value itself is put right behind the loop, off the chain
+                        s = envelope_quotient_finite(N, twoq - tvx2);
                         if (DBG && (expm & 2)) s = N * __builtin_amdgcn_rcpf(twoq - tvx2);  // timing experiment: no division
                         pop = act && !(s > tz) && cnt > 0;  // cnt > 0: the bottom (z = -inf) is never popped
                         if (DBG && (expm & 1)) pop = false;  // timing experiment: no pops
@@ -766,6 +770,7 @@ __device__ __forceinline__ void env_phase(const ColDesc* __restrict__ desc, int 
                             }
                         }
                     } while (__builtin_amdgcn_ballot_w64(pop) != 0ull);
+                    s = __builtin_fmaxf(s, -inf);  // NaN -> -inf, every other value as it is (see above)
                     if (act) {
                         if (cnt == 0) minF = s < minF ? s : minF;  // a test against the bottom entry
                         if (__builtin_expect(cnt - base == C, 0)) evict();

@@ -796,3 +796,26 @@ def test_bench_force_dist_runs_the_rccl_gather_and_passes_its_parity_gate(amd):
     doc = json.loads(out.stdout.strip().splitlines()[-1])
     assert doc["parity_gate"] == "ok" and doc["n_gpus"] == 1 and doc["config"]["matches_per_step"] > 1000
     assert doc["roofline"]["frac"] > 0 and doc["roofline_search"]["achieved"] > 0 and doc["cpu_baseline"]["cores"] >= 1
+
+
+def test_envelope_quotient_is_the_division_for_every_operand_pair(amd, tmp_path):
+    """The L2 sweep's envelope test divides with 4 instructions instead of the compiler's 11 (csrc/fdcm_quotient.h);
+    tools/div_check.hip compares the two bit for bit on every operand pair the sweep can produce (2.75e12 pairs on this
+    GPU's own v_rcp_f32), and its self-test makes sure the comparison can fail."""
+    import json
+    import os
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this machine")
+    exe = str(tmp_path / "div_check")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt",
+                           os.path.join(root, "tools", "div_check.hip"), "-o", exe], timeout=600)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    doc = json.loads(out.stdout.strip().splitlines()[-1])
+    assert out.returncode == 0 and doc["mismatches"] == 0 and doc["pairs_checked"] > 2.7e12, out.stdout[-500:]
+    out = subprocess.run([exe, "selftest"], capture_output=True, text=True, timeout=600)
+    doc = json.loads(out.stdout.strip().splitlines()[-1])
+    assert out.returncode == 0 and doc["mismatches"] > 0, out.stdout[-500:]
