@@ -730,7 +730,8 @@ __device__ __forceinline__ void env_phase(const ColDesc* __restrict__ desc, int 
                     const bool act = q > cs && q <= ce;
                     const float qf = (float)q;
                     const float q2 = qf * qf;  // rounds like the reference's float(long(q * q))
-                    const float hq = fq + q2;
+                    // (a lane outside its range carries NaN through the test: every comparison with it is false, it never pops)
+                    const float hq = act ? fq + q2 : f_nan();
                     const float twoq = qf + qf;
                     float s;
                     bool pop;
@@ -744,11 +745,14 @@ __device__ __forceinline__ void env_phase(const ColDesc* __restrict__ desc, int 
                         // s = ((f[q] + q^2) - f[v] - v^2) / (2q - 2v), left to right in float (imgproc.h:111)
                         const float N = (hq - tf) - tv2;
                         // = N / (2q - 2v) bit for bit in 4 instructions for 11 (fdcm_quotient.h), except that N = -inf (the
-                        // unseeded bottom column of the first segment) comes out as NaN instead of -inf: "not greater than
-                        // tz" either way, and the value itself is put right behind the loop, off the chain
+                        // unseeded bottom column of the first segment) comes out as NaN instead of -inf; the value itself is
+                        // put right behind the loop, off the chain
                         s = envelope_quotient_finite(N, twoq - tvx2);
                         if (DBG && (expm & 2)) s = N * __builtin_amdgcn_rcpf(twoq - tvx2);  // timing experiment: no division
-                        pop = act && !(s > tz) && cnt > 0;  // cnt > 0: the bottom (z = -inf) is never popped
+                        // pop while s <= z[k].  One ordered comparison decides: an inactive lane's s is NaN; the bottom entry's
+                        // z is -inf and s is never -inf (finite, or NaN over the unseeded bottom column), so the bottom is
+                        // never popped -- no test of the lane's range and of cnt > 0 on the chain (three instructions less)
+                        pop = s <= tz;
                         if (DBG && (expm & 1)) pop = false;  // timing experiment: no pops
                         if (pop) {
                             tvf = u.x; tf = u.y; tz = u.z; tv2 = u.w; tvx2 = u.x + u.x;
