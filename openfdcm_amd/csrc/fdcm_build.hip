@@ -578,7 +578,7 @@ __device__ __forceinline__ void desc_lane4(const uint4& d, int j, unsigned long 
 }
 
 // Phase 1 of k_sweep.  smask: seeded columns of the slice, 64 per word (W <= 16384); cj: junction column of
-// segment w per row; ring: stack entries below the top, (float(v), f[v], z, float(v)^2), C per thread.
+// segment w per row; ring: stack entries below the top, (float(2 v), f[v], z, float(v)^2), C per thread.
 template <int C, int NT, bool DBG>
 __device__ __forceinline__ void env_phase(const ColDesc* __restrict__ desc, int W, int H, int HW64, int S, const K2Buf& B,
                                           int expm, unsigned long long* smask, int (*cj)[64], float4 (*ring)[NT]) {
@@ -684,8 +684,8 @@ __device__ __forceinline__ void env_phase(const ColDesc* __restrict__ desc, int 
     ce = max(ce, cs);
     const uint4 db = dp[cs];
     // top entry t and the entry below it u (a register copy of ring entry cnt - 1, so that a single pop needs no
-    // LDS round trip): column (as float), f, z, column^2
-    float tvf = (float)cs;
+    // LDS round trip): twice the column (as float), f, z, column^2
+    float tvf = (float)cs;  // (only for the squares below; the loop carries 2 v: what the test's denominator needs)
     float tf = column_value<true>(((unsigned long long)db.y << 32) | db.x, (int)db.z, (int)db.w, lane, y);
     float tz = -inf;
     float tv2 = tvf * tvf, tvx2 = tvf + tvf;
@@ -697,7 +697,7 @@ __device__ __forceinline__ void env_phase(const ColDesc* __restrict__ desc, int 
     EnvEntry* ent = B.ent + r * (size_t)B.eslots + slot0;
     auto evict = [&]() {
         const float4 e = ring[base & (C - 1)][tid];
-        ent[base] = EnvEntry{(int)e.x, e.y, e.z};
+        ent[base] = EnvEntry{(int)e.x >> 1, e.y, e.z};
         ++base;
         if (DBG) ++n_evict;
     };
@@ -735,6 +735,7 @@ __device__ __forceinline__ void env_phase(const ColDesc* __restrict__ desc, int 
                     const float twoq = qf + qf;
                     float s;
                     bool pop;
+                    unsigned long long any_pop;
                     if (DBG) ++n_cols;
                     // Test at the bottom: one taken branch per extra pass, none on the way out.  A lane that does not pop
                     // recomputes the same s in the passes other lanes still need.  (A fully predicated body -- selects
@@ -754,8 +755,9 @@ __device__ __forceinline__ void env_phase(const ColDesc* __restrict__ desc, int 
                         // never popped -- no test of the lane's range and of cnt > 0 on the chain (three instructions less)
                         pop = s <= tz;
                         if (DBG && (expm & 1)) pop = false;  // timing experiment: no pops
+                        any_pop = __builtin_amdgcn_ballot_w64(pop);  // taken here, from the comparison's own mask
                         if (pop) {
-                            tvf = u.x; tf = u.y; tz = u.z; tv2 = u.w; tvx2 = u.x + u.x;
+                            tvx2 = u.x; tf = u.y; tz = u.z; tv2 = u.w;
                             --cnt;
                             if (cnt > 0) {
                                 if (__builtin_expect(cnt == base, 0)) {  // ring empty: up to four spilled entries come back together
@@ -765,7 +767,7 @@ __device__ __forceinline__ void env_phase(const ColDesc* __restrict__ desc, int 
 #pragma unroll
                                     for (int e = 0; e < 4; ++e) {  // all four are written (the ring is empty; entries below 0 land in free slots): no load stays pending
                                         const float vf = (float)en[e].v;
-                                        ring[(base - 1 - e) & (C - 1)][tid] = make_float4(vf, en[e].f, en[e].z, vf * vf);
+                                        ring[(base - 1 - e) & (C - 1)][tid] = make_float4(vf + vf, en[e].f, en[e].z, vf * vf);
                                     }
                                     base = max(base - 4, 0);
                                     if (DBG) ++n_refill;
@@ -773,15 +775,15 @@ __device__ __forceinline__ void env_phase(const ColDesc* __restrict__ desc, int 
                                 u = ring[(cnt - 1) & (C - 1)][tid];  // needed at the next pop at the earliest
                             }
                         }
-                    } while (__builtin_amdgcn_ballot_w64(pop) != 0ull);
+                    } while (any_pop != 0ull);
                     s = __builtin_fmaxf(s, -inf);  // NaN -> -inf, every other value as it is (see above)
                     if (act) {
                         if (cnt == 0) minF = s < minF ? s : minF;  // a test against the bottom entry
                         if (__builtin_expect(cnt - base == C, 0)) evict();
-                        u = make_float4(tvf, tf, tz, tv2);
+                        u = make_float4(tvx2, tf, tz, tv2);
                         ring[cnt & (C - 1)][tid] = u;
                         ++cnt;
-                        tvf = qf; tf = fq; tz = s; tv2 = q2; tvx2 = twoq;
+                        tf = fq; tz = s; tv2 = q2; tvx2 = twoq;
                     }
                 }
             }
@@ -790,14 +792,14 @@ __device__ __forceinline__ void env_phase(const ColDesc* __restrict__ desc, int 
     if (DBG && lane == 0) dbg[4] = wall_clock64();
     // the top joins the entries; everything still in the ring goes to HBM
     if (cnt - base == C) evict();
-    ring[cnt & (C - 1)][tid] = make_float4(tvf, tf, tz, tv2);
+    ring[cnt & (C - 1)][tid] = make_float4(tvx2, tf, tz, tv2);
     ++cnt;
 #pragma unroll
     for (int e = 0; e < C; ++e) {
         const int i = base + e;
         if (i < cnt) {
             const float4 en = ring[i & (C - 1)][tid];
-            ent[i] = EnvEntry{(int)en.x, en.y, en.z};
+            ent[i] = EnvEntry{(int)en.x >> 1, en.y, en.z};
         }
     }
     const size_t to = (size_t)wave * NR + r;
