@@ -897,26 +897,50 @@ __device__ __forceinline__ void addend_phase(int W, int S, int part_w, const K2B
             if (quirk) {
                 if (DBG) ++n_quirk;
                 // last list entry whose first pixel is <= pend_v, at or after optr: two steps forward (rows along a scene
-                // line need one per entry), else gallop back from the tail (the owner is a few entries back) and bisect
-                if (optr + 1 < lc && (int)(list_pk(optr + 1) >> 16) <= pend_v) {
-                    ++optr;
+                // line need one per entry), else gallop back from the tail (the owner is a few entries back) and bisect.
+                // The entry at optr, the three after it and their addends are read together when they are all in the LDS
+                // window (one LDS round trip; one read at a time made up to five, each waited for): the steps and the
+                // owner's record are then selects.
+                unsigned pk;
+                float ob;
+                bool far;  // a third step forward would still not be far enough
+                if (__builtin_expect(optr >= lc - KL, 1)) {
+                    const int i1 = min(optr + 1, lc - 1), i2 = min(optr + 2, lc - 1), i3 = min(optr + 3, lc - 1);
+                    const unsigned pk0 = l_pk[optr & (KL - 1)][lane], pk1 = l_pk[i1 & (KL - 1)][lane], pk2 = l_pk[i2 & (KL - 1)][lane],
+                                   pk3 = l_pk[i3 & (KL - 1)][lane];
+                    const float b0 = l_b[optr & (KL - 1)][lane], b1 = l_b[i1 & (KL - 1)][lane], b2 = l_b[i2 & (KL - 1)][lane];
+                    if (DBG) n_probe += 4;
+                    const bool a1 = optr + 1 < lc && (int)(pk1 >> 16) <= pend_v;
+                    const bool a2 = a1 && optr + 2 < lc && (int)(pk2 >> 16) <= pend_v;
+                    far = a2 && optr + 3 < lc && (int)(pk3 >> 16) <= pend_v;
+                    optr += (a1 ? 1 : 0) + (a2 ? 1 : 0);
+                    pk = a2 ? pk2 : (a1 ? pk1 : pk0);
+                    ob = a2 ? b2 : (a1 ? b1 : b0);
+                } else {
+                    far = false;
                     if (optr + 1 < lc && (int)(list_pk(optr + 1) >> 16) <= pend_v) {
                         ++optr;
                         if (optr + 1 < lc && (int)(list_pk(optr + 1) >> 16) <= pend_v) {
-                            int hi = lc - 1, lo = hi, step = 1;
-                            while (lo > optr && (int)(list_pk(lo) >> 16) > pend_v) { hi = lo - 1; lo = max(optr, lo - step); step <<= 1; }
-                            while (lo < hi) {
-                                const int mid = (lo + hi + 1) >> 1;
-                                if ((int)(list_pk(mid) >> 16) <= pend_v) lo = mid; else hi = mid - 1;
-                            }
-                            optr = lo;
+                            ++optr;
+                            far = optr + 1 < lc && (int)(list_pk(optr + 1) >> 16) <= pend_v;
                         }
                     }
+                    pk = 0u; ob = 0.f;
+                    if (!far) { pk = list_pk(optr); ob = list_b(optr); }
+                }
+                if (far) {
+                    int hi = lc - 1, lo = hi, step = 1;
+                    while (lo > optr && (int)(list_pk(lo) >> 16) > pend_v) { hi = lo - 1; lo = max(optr, lo - step); step <<= 1; }
+                    while (lo < hi) {
+                        const int mid = (lo + hi + 1) >> 1;
+                        if ((int)(list_pk(mid) >> 16) <= pend_v) lo = mid; else hi = mid - 1;
+                    }
+                    optr = lo;
+                    pk = list_pk(optr); ob = list_b(optr);
                 }
                 if (DBG && lc - optr > KL) ++n_far;
-                const unsigned pk = list_pk(optr);
                 const float dv = (float)(pend_v - (int)(pk & 0xffffu));  // dv * dv rounds like float(long(dv * dv))
-                b = list_b(optr) + dv * dv;
+                b = ob + dv * dv;
             }
         }
         if (owns) {
@@ -932,9 +956,16 @@ __device__ __forceinline__ void addend_phase(int W, int S, int part_w, const K2B
     };
     auto flush = [&]() {  // ring -> HBM: all lanes together, in list order
         const int fmax = __builtin_amdgcn_readfirstlane(wave_max(lc - flushed));
-        for (int e = 0; e < fmax; ++e) {
-            const int i = flushed + e;
-            if (i < lc && writer && !(xp & 1)) own[i] = OwnEntry{l_pk[i & (KL - 1)][lane], l_b[i & (KL - 1)][lane]};
+        for (int e = 0; e < fmax; e += 4) {  // four entries per LDS round trip (slots past lc hold older entries: read, not stored)
+            unsigned pk4[4];
+            float b4[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { pk4[j] = l_pk[(flushed + e + j) & (KL - 1)][lane]; b4[j] = l_b[(flushed + e + j) & (KL - 1)][lane]; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = flushed + e + j;
+                if (i < lc && writer && !(xp & 1)) own[i] = OwnEntry{pk4[j], b4[j]};
+            }
         }
         flushed = lc;
     };
