@@ -745,14 +745,11 @@ __device__ __forceinline__ void env_phase(const ColDesc* __restrict__ desc, int 
                         if (DBG) ++n_iter;
                         // s = ((f[q] + q^2) - f[v] - v^2) / (2q - 2v), left to right in float (imgproc.h:111)
                         const float N = (hq - tf) - tv2;
-                        // = N / (2q - 2v) bit for bit in 4 instructions for 11 (fdcm_quotient.h), except that N = -inf (the
-                        // unseeded bottom column of the first segment) comes out as NaN instead of -inf; the value itself is
-                        // put right behind the loop, off the chain
-                        s = envelope_quotient_finite(N, twoq - tvx2);
+                        s = envelope_quotient(N, twoq - tvx2);  // = N / (2q - 2v) bit for bit, in 4 instructions for 11 (fdcm_quotient.h)
                         if (DBG && (expm & 2)) s = N * __builtin_amdgcn_rcpf(twoq - tvx2);  // timing experiment: no division
                         // pop while s <= z[k].  One ordered comparison decides: an inactive lane's s is NaN; the bottom entry's
-                        // z is -inf and s is never -inf (finite, or NaN over the unseeded bottom column), so the bottom is
-                        // never popped -- no test of the lane's range and of cnt > 0 on the chain (three instructions less)
+                        // z is -inf and s is finite (about -FLT_MAX / D over a seedless bottom column), so the bottom is never
+                        // popped -- no test of the lane's range and of cnt > 0 on the chain (three instructions less)
                         pop = s <= tz;
                         if (DBG && (expm & 1)) pop = false;  // timing experiment: no pops
                         any_pop = __builtin_amdgcn_ballot_w64(pop);  // taken here, from the comparison's own mask
@@ -776,7 +773,6 @@ __device__ __forceinline__ void env_phase(const ColDesc* __restrict__ desc, int 
                             }
                         }
                     } while (any_pop != 0ull);
-                    s = __builtin_fmaxf(s, -inf);  // NaN -> -inf, every other value as it is (see above)
                     if (act) {
                         if (cnt == 0) minF = s < minF ? s : minF;  // a test against the bottom entry
                         if (__builtin_expect(cnt - base == C, 0)) evict();

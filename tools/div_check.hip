@@ -2,9 +2,10 @@
 // (fdcm_build.hip: envelope_quotient) returns the IEEE quotient for every operand pair the sweep can produce:
 //   D = 2 (q - v): every even integer in [2, 2 * 16383]   (columns are < 2^14)
 //   N = (f_q + q^2) - f_v - v^2: an integer-valued float with |N| < 2^32 (sums and differences of squared distances and
-//       squared columns, each < 2^29, rounded to float at every step -- so above 2^24 only the representable integers)
-// (and N = -inf once per D: the unseeded bottom column).  This program compares the two for all of them (2.75e12 pairs,
-// seconds); `div_check selftest` runs the same comparison on the uncorrected quotient, which must fail.
+//       squared columns, each < 2^29, rounded to float at every step -- so above 2^24 only the representable integers),
+//       or -FLT_MAX (over the seedless bottom column of a row's first segment: f = FLT_MAX absorbs the other terms)
+// This program compares the two for all of them (2.75e12 pairs, seconds); `div_check selftest` runs the same comparison on
+// the uncorrected quotient, which must fail.
 //   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt tools/div_check.hip -o div_check && ./div_check
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -34,7 +35,7 @@ __global__ void k_check(unsigned long long* bad, unsigned long long* first_bad, 
         const float D = (float)(2 * d);
         const float r1 = a / D, s1 = SELFTEST ? short_quotient(a, D) : fdcm::envelope_quotient(a, D);
         // (N = -0 cannot occur: N is a difference of non-negative values, and x - x is +0; -0 / D = -0 is the one pair the
-        // refinement gets differently, +0)
+        // short form gets differently, +0)
         const float na = i == 0 ? a : -a;
         const float r2 = na / D, s2 = SELFTEST ? short_quotient(na, D) : fdcm::envelope_quotient(na, D);
         if (__float_as_uint(r1) != __float_as_uint(s1) || __float_as_uint(r2) != __float_as_uint(s2)) {
@@ -42,10 +43,10 @@ __global__ void k_check(unsigned long long* bad, unsigned long long* first_bad, 
             ++nb;
         }
     }
-    if (i == 0) {  // N = -inf: the division gives -inf
+    if (i == 0) {  // N = -FLT_MAX: what the test sees over the seedless bottom column of a row's first segment (f = FLT_MAX absorbs the rest)
         for (int d = d_from; d < d_to; ++d) {
-            const float D = (float)(2 * d), ninf = -__builtin_inff();
-            if (__float_as_uint(ninf / D) != __float_as_uint(fdcm::envelope_quotient(ninf, D))) ++nb;
+            const float D = (float)(2 * d), big = -3.402823466e+38f;
+            if (__float_as_uint(big / D) != __float_as_uint(SELFTEST ? short_quotient(big, D) : fdcm::envelope_quotient(big, D))) ++nb;
         }
     }
     if (nb) atomicAdd(bad, nb);
