@@ -131,7 +131,7 @@ __global__ void __launch_bounds__(256) k_coldesc(unsigned long long* __restrict_
 // contiguous; the wave-per-column kernel writes 16 bytes every W * 16).
 template <int SEG, int XT>  // XT columns per block: 64, or 32 when a column has 64 words (32 KB of LDS instead of 64)
 __global__ void __launch_bounds__(256) k_coldesc_tile(unsigned long long* __restrict__ bitmap, ColDesc* __restrict__ desc,
-                                                      int W, int HW64) {
+                                                      int W, int HW64, unsigned* __restrict__ colmask) {
     extern __shared__ uint4 tile[];  // [word][XT columns], rows padded by one unit (bank spread)
     constexpr int STR = XT + 1;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -165,6 +165,19 @@ __global__ void __launch_bounds__(256) k_coldesc_tile(unsigned long long* __rest
     for (int idx = threadIdx.x; idx < HW64 * XT; idx += 256) {
         const int w = idx / XT, xl = idx - w * XT;
         if (x0 + xl < W) out[((size_t)k * HW64 + w) * W + x0 + xl] = tile[w * STR + xl];
+    }
+    // The slice's seeded columns, one bit per column ((W + 63) / 64 words of 64 bits per slice, written as 32-bit halves):
+    // the L2 sweep skips the others, and every one of its workgroups used to rebuild this mask from the descriptors.
+    if (colmask && wave == 0) {
+        const bool seeded = lane < XT && x0 + lane < W && !desc_seedless(tile[min(lane, XT - 1)]);  // chunk 0's descriptor says it for the column
+        const unsigned long long mk = __ballot(seeded);
+        unsigned* dst = colmask + ((size_t)k * ((W + 63) >> 6) + (x0 >> 6)) * 2;
+        if (XT == 64) { if (lane < 2) dst[lane] = lane ? (unsigned)(mk >> 32) : (unsigned)mk; }
+        else {
+            const int half = (x0 >> 5) & 1;
+            if (lane == 0) dst[half] = (unsigned)mk;
+            if (lane == 1 && half == 0 && x0 + 32 >= W) dst[1] = 0u;  // no block for the word's upper half
+        }
     }
 }
 
@@ -562,6 +575,7 @@ struct K2Buf {
     long NR;                              // rows of the scratch arrays (chunks * 64)
     int eslots, lslots;
     int addend_waves;                     // waves of a block that share the addend pass (a power of two; 0 = all of them)
+    const unsigned long long* colmask;    // [slice][(W + 63) / 64]: the slice's seeded columns (k_coldesc_tile), or null
 };
 
 __device__ __forceinline__ unsigned long long uni64(unsigned long long v) {
@@ -597,11 +611,15 @@ __device__ __forceinline__ void env_phase(const ColDesc* __restrict__ desc, int 
     long long sc0 = 0;
     if (DBG && lane == 0) { dbg[0] = wall_clock64(); sc0 = clock64(); }
     if (tid == 0) B.flags[chunk] = 0;
-    for (int b = wave; b < nwords; b += S) {
-        const int x = b * 64 + lane;
-        const uint4 d = dp[min(x, W - 1)];
-        const unsigned long long mk = __ballot(x < W && !desc_seedless(d));
-        if (lane == 0) smask[b] = mk;
+    if (B.colmask) {  // (H <= 4096: the descriptor kernel left the mask)
+        for (int b = tid; b < nwords; b += NT) smask[b] = B.colmask[(size_t)k * nwords + b];
+    } else {
+        for (int b = wave; b < nwords; b += S) {
+            const int x = b * 64 + lane;
+            const uint4 d = dp[min(x, W - 1)];
+            const unsigned long long mk = __ballot(x < W && !desc_seedless(d));
+            if (lane == 0) smask[b] = mk;
+        }
     }
     __syncthreads();
     if (DBG && lane == 0) dbg[1] = wall_clock64();
@@ -1729,6 +1747,7 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after) {
     if (env_segments >= 1 && env_segments <= kSegMax) S = env_segments;
     const int part_w = (((W + kFillParts - 1) / kFillParts) + 3) & ~3;  // fill parts start on a group of 4 columns
     fm->coldesc.reserve((size_t)ncols * HW64 * sizeof(ColDesc));
+    fm->colmask.reserve((size_t)m * ((W + 63) / 64) * 8);
     K2Buf kb{};
     bool proxy_order = false;
     int* order_dst = nullptr;
@@ -1817,9 +1836,11 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after) {
         const int XT = HW64 > 32 ? 32 : 64;
         const dim3 grid((unsigned)((W + XT - 1) / XT), (unsigned)m);
         const size_t lds = (size_t)HW64 * (XT + 1) * sizeof(uint4);
-        if (HW64 <= 16) hipLaunchKernelGGL((k_coldesc_tile<16, 64>), grid, dim3(256), lds, st, bm, d_desc, W, HW64);
-        else if (HW64 <= 32) hipLaunchKernelGGL((k_coldesc_tile<32, 64>), grid, dim3(256), lds, st, bm, d_desc, W, HW64);
-        else hipLaunchKernelGGL((k_coldesc_tile<64, 32>), grid, dim3(256), lds, st, bm, d_desc, W, HW64);
+        unsigned* cm = (unsigned*)fm->colmask.p;
+        kb.colmask = (const unsigned long long*)fm->colmask.p;
+        if (HW64 <= 16) hipLaunchKernelGGL((k_coldesc_tile<16, 64>), grid, dim3(256), lds, st, bm, d_desc, W, HW64, cm);
+        else if (HW64 <= 32) hipLaunchKernelGGL((k_coldesc_tile<32, 64>), grid, dim3(256), lds, st, bm, d_desc, W, HW64, cm);
+        else hipLaunchKernelGGL((k_coldesc_tile<64, 32>), grid, dim3(256), lds, st, bm, d_desc, W, HW64, cm);
     } else {
         hipLaunchKernelGGL(k_coldesc, dim3((unsigned)((ncols + 3) / 4)), dim3(256), 0, st,
                            fm->bitmap.as<unsigned long long>(), d_desc, W, HW64, ncols);

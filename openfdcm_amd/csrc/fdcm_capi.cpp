@@ -62,7 +62,7 @@ static void destroy(fdcm_featuremap* fm) {
     if (!fm) return;
     (void)hipSetDevice(fm->device);
     if (fm->stream) (void)hipStreamSynchronize(fm->stream);
-    fm->vol.release(); fm->ivol.release(); fm->bitmap.release(); fm->coldesc.release(); fm->offtab.release(); fm->stack.release(); fm->plan.release(); fm->stage.release();
+    fm->vol.release(); fm->ivol.release(); fm->bitmap.release(); fm->coldesc.release(); fm->colmask.release(); fm->offtab.release(); fm->stack.release(); fm->plan.release(); fm->stage.release();
     fm->s_scene.release(); fm->s_pairs.release(); fm->s_records.release(); fm->s_flags.release(); fm->s_out.release(); fm->s_work.release(); fm->s_tail.release(); fm->s_tail_out.release(); fm->s_eval.release();
     fm->s_counter.release(); fm->s_stage.release(); fm->s_cnt.release(); fm->s_bins.release(); fm->s_bins_stage.release();
     if (fm->timing.created)

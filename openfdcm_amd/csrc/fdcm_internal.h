@@ -133,6 +133,7 @@ struct fdcm_featuremap {
     bool current_interleaved() const { return vol_stage >= 2 || (vol_stage == 1 && vol1_interleaved); }
     fdcm::DevBuf bitmap;   // m*W*ceil(H/64) uint64 seed bits along y
     fdcm::DevBuf coldesc;  // m*ceil(H/64)*W column-chunk descriptors (16 B)
+    fdcm::DevBuf colmask;  // m*ceil(W/64) words: the seeded columns of every slice (k_coldesc_tile, for the L2 sweep)
     fdcm::DevBuf offtab;   // per slice: one word per group of 4 columns for the shallow sweeps of the line integral (k_groups)
     fdcm::DevBuf stack;    // K2 scratch: per row a (v, f, z) stack of W entries
     fdcm::DevBuf plan;     // RasterLine[] | PropStep[] | IntegralDesc[] | keys[]

@@ -819,3 +819,22 @@ def test_envelope_quotient_is_the_division_for_every_operand_pair(amd, tmp_path)
     out = subprocess.run([exe, "selftest"], capture_output=True, text=True, timeout=600)
     doc = json.loads(out.stdout.strip().splitlines()[-1])
     assert out.returncode == 0 and doc["mismatches"] > 0, out.stdout[-500:]
+
+
+@pytest.mark.parametrize("size", [2060, 2081, 2112, 3000, 4096])
+def test_sizes_around_the_descriptor_tiles(amd, size):
+    """Feature sizes above 2048 rows take the 32-column descriptor tiles, whose workgroups each write half a word of the
+    slice's seeded-column mask (the L2 sweep skips the other columns): widths that end in the lower half of a word, in the
+    upper half, on a word, and the largest size of that kernel, whole volume against the oracle."""
+    from openfdcm_amd.engine import DeviceFeatureMap
+    rng = np.random.default_rng(size)
+    p = rng.uniform(0, 1, size=(24, 4)).astype(np.float32)
+    lines = (p * np.float32(size - 1)).astype(np.float32)
+    lines[0] = [0, 0, 5, 3]
+    lines[1] = [size - 1, size - 1, size - 7, size - 4]
+    scene = np.ascontiguousarray(lines.T)
+    for dist in (0, 1):
+        dev = DeviceFeatureMap.build(scene, depth=2, coeff=5.0, padding=1.0, distance=dist)
+        orc = O.build(scene, depth=2, coeff=5.0, padding=1.0, distance=dist, nthreads=8)
+        assert dev.volume().shape[1] == size
+        assert_volume_equal(dev, orc, f"size {size} distance {dist}")
