@@ -38,9 +38,12 @@ for k in range(m):
             d = np.where(yy < y0, y0 - yy, np.where(yy > y1, yy - y1, 0))
             lb.append(d.min())
         lb = np.array(lb, dtype=np.float64) if lb else np.zeros(1)
-        feats.append((n_seeded, n_far, lb.mean(), np.minimum(lb, 256).sum(), (lb > 64).sum(), (lb > 128).sum(), (lb > 256).sum()))
+        n_in_px = int(seed[k, :, y0:y1 + 1].sum())      # seed pixels inside the chunk (~ owner entries of its rows)
+        rows_px = seed[k, :, y0:y1 + 1].sum(axis=0)
+        feats.append((n_seeded, n_far, lb.mean(), np.minimum(lb, 256).sum(), (lb > 64).sum(), (lb > 128).sum(), (lb > 256).sum(),
+                      int(inside.sum()), n_in_px, int(rows_px.max())))
 F = np.array(feats, dtype=np.float64)
-names = ["n_seeded", "n_far", "mean_lb", "sum_min(lb,256)", "n(lb>64)", "n(lb>128)", "n(lb>256)"]
+names = ["n_seeded", "n_far", "mean_lb", "sum_min(lb,256)", "n(lb>64)", "n(lb>128)", "n(lb>256)", "n_inside_cols", "n_inside_px", "max_row_px"]
 print("chunks", cost.size, "cost us: mean %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f" % (cost.mean(), *np.percentile(cost, [50, 90, 99]), cost.max()))
 for i, n in enumerate(names):
     r = np.corrcoef(F[:, i], cost)[0, 1]
@@ -49,7 +52,7 @@ A = np.column_stack([F, np.ones(len(F))])
 coef, *_ = np.linalg.lstsq(A, cost, rcond=None)
 pred = A @ coef
 print("  least squares:", dict(zip(names + ["1"], np.round(coef, 4))), "corr %.3f" % np.corrcoef(pred, cost)[0, 1])
-for cols in ([0, 1], [0, 3], [0, 1, 3], [0, 4, 5, 6]):
+for cols in ([0, 1], [0, 3], [0, 1, 3], [0, 4, 5, 6], [0, 1, 7], [0, 1, 8], [0, 1, 9], [0, 1, 7, 9]):
     A2 = np.column_stack([F[:, cols], np.ones(len(F))])
     c2, *_ = np.linalg.lstsq(A2, cost, rcond=None)
     print("  fit on", [names[j] for j in cols], np.round(c2, 4), "corr %.3f" % np.corrcoef(A2 @ c2, cost)[0, 1])
