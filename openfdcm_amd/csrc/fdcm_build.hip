@@ -931,16 +931,28 @@ __device__ __forceinline__ void addend_phase(int W, int S, int part_w, const K2B
                     pk = a2 ? pk2 : (a1 ? pk1 : pk0);
                     ob = a2 ? b2 : (a1 ? b1 : b0);
                 } else {
-                    far = false;
-                    if (optr + 1 < lc && (int)(list_pk(optr + 1) >> 16) <= pend_v) {
-                        ++optr;
-                        if (optr + 1 < lc && (int)(list_pk(optr + 1) >> 16) <= pend_v) {
-                            ++optr;
-                            far = optr + 1 < lc && (int)(list_pk(optr + 1) >> 16) <= pend_v;
-                        }
-                    }
-                    pk = 0u; ob = 0.f;
-                    if (!far) { pk = list_pk(optr); ob = list_b(optr); }
+                    // The pointer is more than the LDS window behind the list's end (rows whose envelope lags its columns by
+                    // more than 64 pixels: the diagonals' longest blocks): the same four entries, from the list in HBM where
+                    // they have left the window -- one trip to memory for all four, consumed in place, where one read at a
+                    // time made three to five, each waiting for everything else in flight (the next batch of the walk).
+                    const int i1 = min(optr + 1, lc - 1), i2 = min(optr + 2, lc - 1), i3 = min(optr + 3, lc - 1);
+                    const OwnEntry h0 = own[optr], h1 = own[i1], h2 = own[i2], h3 = own[i3];  // (slots not flushed yet: read, not used)
+                    unsigned hp0, hp1, hp2, hp3;
+                    float hb0, hb1, hb2;
+                    asm volatile("v_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %6\n\tv_mov_b32 %3, %7"
+                                 : "=v"(hp0), "=v"(hp1), "=v"(hp2), "=v"(hp3) : "v"(h0.pk), "v"(h1.pk), "v"(h2.pk), "v"(h3.pk));
+                    asm volatile("v_mov_b32 %0, %3\n\tv_mov_b32 %1, %4\n\tv_mov_b32 %2, %5" : "=v"(hb0), "=v"(hb1), "=v"(hb2) : "v"(h0.b), "v"(h1.b), "v"(h2.b));
+                    if (DBG) { n_probe += 4; n_hbm += 4; }
+                    const bool w1 = i1 >= lc - KL, w2 = i2 >= lc - KL, w3 = i3 >= lc - KL;  // (optr itself is behind the window here)
+                    const unsigned pk0 = hp0, pk1 = w1 ? l_pk[i1 & (KL - 1)][lane] : hp1, pk2 = w2 ? l_pk[i2 & (KL - 1)][lane] : hp2,
+                                   pk3 = w3 ? l_pk[i3 & (KL - 1)][lane] : hp3;
+                    const float b0 = hb0, b1 = w1 ? l_b[i1 & (KL - 1)][lane] : hb1, b2 = w2 ? l_b[i2 & (KL - 1)][lane] : hb2;
+                    const bool a1 = optr + 1 < lc && (int)(pk1 >> 16) <= pend_v;
+                    const bool a2 = a1 && optr + 2 < lc && (int)(pk2 >> 16) <= pend_v;
+                    far = a2 && optr + 3 < lc && (int)(pk3 >> 16) <= pend_v;
+                    optr += (a1 ? 1 : 0) + (a2 ? 1 : 0);
+                    pk = a2 ? pk2 : (a1 ? pk1 : pk0);
+                    ob = a2 ? b2 : (a1 ? b1 : b0);
                 }
                 if (far) {
                     int hi = lc - 1, lo = hi, step = 1;
