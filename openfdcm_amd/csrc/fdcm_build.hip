@@ -1336,6 +1336,105 @@ __global__ void __launch_bounds__(256) k_l1_backward(float* __restrict__ vol, in
     }
 }
 
+// ---- The two L1 sweeps with ONE pass over the volume (round 3).
+// The forward sweep is F[x] = min(c[x], F[x-1] + 1) on the column values c (exact integers, or FLT_MAX for a seedless column,
+// which absorbs every +1 and +-x), the backward one R[x] = min(F[x], R[x+1] + 1) on its result (imgproc.h:138-145).  As two
+// kernels they write V, read V and write V again; the 24 GB of config 5 went at the rate of a plain copy (2.4 + 4.9 ms).
+// Both recurrences only carry one number per row across a cut: F[x0 - 1] = min over x' < x0 of (c[x'] - x') + (x0 - 1), and
+// for the backward one R[x1 + 1] may be replaced by B[x1 + 1] = min over x' > x1 of (c[x'] + x') - (x1 + 1), the plain
+// backward scan of c (R[x1] = min(F[x1], F[x1+1] + 1, B[x1+1] + 1) and F[x1+1] + 1 = min(c[x1+1] + 1, F[x1] + 2) is never
+// below min(F[x1], B[x1+1] + 1)).  All terms are integers below 2^24 or FLT_MAX: every float operation is exact, so the
+// regrouping changes no bit.  So: the two minima per (row, 64-column word) from the descriptors alone (k_l1_word_mins),
+// their exclusive prefix / suffix minima over the words of a row (k_l1_carries, 3 % of V), and then every word by itself:
+// c from the descriptors, forward from its carry into 64 registers, backward from its carry, one store (k_l1_word).
+__device__ __forceinline__ float l1_column_value(const ColDesc& dcur, unsigned long long nz, int j, int lane, int y) {
+    if ((nz >> j) & 1ull) {  // a seed inside the chunk's 64 rows (wave-uniform): the bit scans
+        unsigned long long wc;
+        int pc, nc;
+        desc_lane(dcur, j, wc, pc, nc);
+        return column_value<false>(wc, pc, nc, lane, y);
+    }
+    const int pc = __builtin_amdgcn_readlane(dcur.prev, j), nc = __builtin_amdgcn_readlane(dcur.next, j);
+    const int d = min(y - pc, nc - y);
+    return d >= (1 << 29) ? FLT_MAX : (float)d;  // no seed in the whole column
+}
+__global__ void __launch_bounds__(256) k_l1_word_mins(const ColDesc* __restrict__ desc, float2* __restrict__ mins, int W, int HW64,
+                                                      int nwords, long nwaves) {
+    const int lane = threadIdx.x & 63;
+    const long wid = (long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    if (wid >= nwaves) return;
+    const long kc = wid / nwords;  // slice * HW64 + chunk
+    const int w = (int)(wid - kc * nwords), c = (int)(kc % HW64), y = c * 64 + lane;
+    const int x0 = w * 64, jn = min(64, W - x0);
+    const ColDesc dcur = desc[(size_t)kc * W + min(x0 + lane, W - 1)];
+    const unsigned long long nz = __builtin_amdgcn_ballot_w64(dcur.word != 0ull);
+    float a = FLT_MAX, b = FLT_MAX;
+    for (int j = 0; j < jn; ++j) {
+        const float cq = l1_column_value(dcur, nz, j, lane, y), xf = (float)(x0 + j);
+        a = std_min(a, cq - xf);
+        b = std_min(b, cq + xf);
+    }
+    mins[(size_t)wid * 64 + lane] = make_float2(a, b);
+}
+// in place: .x <- min of the .x of the words before, .y <- min of the .y of the words behind (FLT_MAX where there is none)
+__global__ void __launch_bounds__(256) k_l1_carries(float2* __restrict__ mins, int nwords, long nrows) {
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;  // (slice * HW64 + chunk) * 64 + row
+    if (gid >= nrows) return;
+    float2* m = mins + (size_t)(gid >> 6) * nwords * 64 + (gid & 63);
+    float p = FLT_MAX;
+    for (int w = 0; w < nwords; ++w) { const float t = m[(size_t)w * 64].x; m[(size_t)w * 64].x = p; p = std_min(p, t); }
+    float q = FLT_MAX;
+    for (int w = nwords - 1; w >= 0; --w) { const float t = m[(size_t)w * 64].y; m[(size_t)w * 64].y = q; q = std_min(q, t); }
+}
+template <bool FULL>  // FULL: the word has all 64 columns (every word but a row's last one)
+__device__ __forceinline__ void l1_word(const ColDesc& dcur, unsigned long long nz, float2 carry, int x0, int jn, int lane, int y,
+                                        __amdgpu_buffer_rsrc_t rs, unsigned vrow, int grpB) {
+    float f[64];
+    float run = carry.x + (float)(x0 - 1);  // F[x0 - 1]; FLT_MAX in front of the row's first column: min(c, FLT_MAX + 1) = c
+#pragma unroll
+    for (int j = 0; j < 64; ++j) {
+        f[j] = 0.f;  // (columns past W are padding and hold 0)
+        if (FULL || j < jn) {
+            run = std_min(l1_column_value(dcur, nz, j, lane, y), run + 1);
+            f[j] = run;
+        }
+    }
+    float r = carry.y - (float)(x0 + jn);  // B[x1 + 1]; FLT_MAX behind the row's last column: min(F, FLT_MAX + 1) = F
+#pragma unroll
+    for (int j = 63; j >= 0; --j) {
+        if (FULL || j < jn) {
+            r = std_min(f[j], r + 1);
+            f[j] = r;
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+        if (FULL || 4 * g < jn) {
+            u32x4 out;
+            out.x = __float_as_uint(f[4 * g]); out.y = __float_as_uint(f[4 * g + 1]); out.z = __float_as_uint(f[4 * g + 2]); out.w = __float_as_uint(f[4 * g + 3]);
+            __builtin_amdgcn_raw_buffer_store_b128(out, rs, vrow + (unsigned)(((x0 >> 2) + g) * grpB), 0, 0);  // (no scalar offset: see store_unit_note)
+        }
+    }
+}
+__global__ void __launch_bounds__(256) k_l1_word(const ColDesc* __restrict__ desc, const float2* __restrict__ carries, float* __restrict__ vol,
+                                                 int W, int H, int HW64, int nwords, long nwaves) {
+    const int lane = threadIdx.x & 63;
+    const long wid = (long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    if (wid >= nwaves) return;
+    const long kc = wid / nwords;
+    const long k = kc / HW64;
+    const int w = (int)(wid - kc * nwords), c = (int)(kc - k * HW64), y = c * 64 + lane;
+    const int x0 = w * 64, jn = min(64, W - x0);
+    const ColDesc dcur = desc[(size_t)kc * W + min(x0 + lane, W - 1)];
+    const float2 carry = carries[(size_t)wid * 64 + lane];
+    const unsigned long long nz = __builtin_amdgcn_ballot_w64(dcur.word != 0ull);
+    const size_t sl = ivol_slice_floats(W, H);
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc(vol + (size_t)k * sl, 0, (unsigned)(sl * 4), 0x00020000);
+    const unsigned vrow = y < H ? (unsigned)y * 16u : 0x80000000u;  // rows past the image: dropped stores
+    if (jn == 64) l1_word<true>(dcur, nz, carry, x0, jn, lane, y, rs, vrow, H * 16);
+    else l1_word<false>(dcur, nz, carry, x0, jn, lane, y, rs, vrow, H * 16);
+}
+
 __global__ void k_sqrt(float* __restrict__ vol, size_t n) {  // only for staged (test) builds
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) vol[i] = sqrtf(vol[i]);
@@ -1759,6 +1858,7 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after) {
     if (env_segments >= 1 && env_segments <= kSegMax) S = env_segments;
     const int part_w = (((W + kFillParts - 1) / kFillParts) + 3) & ~3;  // fill parts start on a group of 4 columns
     fm->coldesc.reserve((size_t)ncols * HW64 * sizeof(ColDesc));
+    if (fm->distance == FDCM_L1) fm->stack.reserve((size_t)m * HW64 * ((W + 63) / 64) * 64 * sizeof(float2));  // the L1 pass's minima / carries
     fm->colmask.reserve((size_t)m * ((W + 63) / 64) * 8);
     K2Buf kb{};
     bool proxy_order = false;
@@ -1861,7 +1961,16 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after) {
     FDCM_HIP(hipEventRecord(ev[2], st));
     {
         const unsigned wblocks = (unsigned)((nwaves + 3) / 4);
-        if (fm->distance == FDCM_L1) {
+        static const bool env_l1_two_sweeps = getenv("FDCM_L1_TWO_SWEEPS") != nullptr;  // measurement: the forward and the backward kernel
+        if (fm->distance == FDCM_L1 && !env_l1_two_sweeps) {
+            // one pass over the volume: minima per (row, word), their prefix / suffix over the row's words, then word by word
+            const int nwords = (W + 63) / 64;
+            const long wwaves = (long)m * HW64 * nwords;
+            float2* mins = (float2*)fm->stack.p;  // reserved above
+            hipLaunchKernelGGL(k_l1_word_mins, dim3((unsigned)((wwaves + 3) / 4)), dim3(256), 0, st, d_desc, mins, W, HW64, nwords, wwaves);
+            hipLaunchKernelGGL(k_l1_carries, dim3((unsigned)(((long)m * HW64 * 64 + 255) / 256)), dim3(256), 0, st, mins, nwords, (long)m * HW64 * 64);
+            hipLaunchKernelGGL(k_l1_word, dim3((unsigned)((wwaves + 3) / 4)), dim3(256), 0, st, d_desc, (const float2*)mins, vol, W, H, HW64, nwords, wwaves);
+        } else if (fm->distance == FDCM_L1) {
             hipLaunchKernelGGL(k_l1_forward, dim3(wblocks), dim3(256), 0, st, d_desc, vol, W, H, HW64, nwaves);
             {
                 const long bwaves = (long)m * ((H + 63) / 64);  // 64 rows of one slice per wave
