@@ -833,8 +833,24 @@ def test_sizes_around_the_descriptor_tiles(amd, size):
     lines[0] = [0, 0, 5, 3]
     lines[1] = [size - 1, size - 1, size - 7, size - 4]
     scene = np.ascontiguousarray(lines.T)
-    for dist in (0, 1):
+    for dist in (0, 1, 2):  # (L1 too: its word-by-word pass has a partial last word at the same sizes)
         dev = DeviceFeatureMap.build(scene, depth=2, coeff=5.0, padding=1.0, distance=dist)
         orc = O.build(scene, depth=2, coeff=5.0, padding=1.0, distance=dist, nthreads=8)
         assert dev.volume().shape[1] == size
         assert_volume_equal(dev, orc, f"size {size} distance {dist}")
+
+
+@pytest.mark.parametrize("size", [63, 65, 130, 5000])
+def test_l1_single_pass_sizes(amd, size):
+    """The L1 transform as one pass over the volume (per-word minima, carries over the words of a row, word by word): one
+    word and a bit, less than a word, and a height above 4096 rows (the other descriptor kernel), whole volume."""
+    from openfdcm_amd.engine import DeviceFeatureMap
+    rng = np.random.default_rng(size)
+    p = rng.uniform(0, 1, size=(12, 4)).astype(np.float32)
+    lines = (p * np.float32(size - 1)).astype(np.float32)
+    lines[0] = [0, 0, 5, 3]
+    lines[1] = [size - 1, size - 1, size - 7, size - 4]
+    scene = np.ascontiguousarray(lines.T)
+    dev = DeviceFeatureMap.build(scene, depth=2, coeff=5.0, padding=1.0, distance=2)
+    orc = O.build(scene, depth=2, coeff=5.0, padding=1.0, distance=2, nthreads=8)
+    assert_volume_equal(dev, orc, f"L1 size {size}")
