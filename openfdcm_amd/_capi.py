@@ -8,7 +8,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfdcm_hip.so")
+# FDCM_LIBRARY selects another build of the same library (the lab build of `make LAB=1`, for tools/)
+LIB_PATH = os.environ.get("FDCM_LIBRARY") or os.path.join(_HERE, "libfdcm_hip.so")
 
 FDCM_OK = 0
 L2, L2_SQUARED, L1 = 0, 1, 2

@@ -22,12 +22,13 @@
 #include <cstdlib>
 #include <cstring>
 
+#include "fdcm_build_dev.h"
 #include "fdcm_internal.h"
 #include "fdcm_quotient.h"
+#include "fdcm_sweep.h"
 
 namespace fdcm {
 
-static constexpr int kWave = 64;
 
 // ------------------------------------------------------------------------------------------ K0
 // drawLines (drawing.h:111-125): one block per clipped line, threads over its raster points.
@@ -50,47 +51,6 @@ __global__ void k_seeds(const RasterLine* __restrict__ lines, unsigned long long
 // (every envelope owner is a seed and owns itself), or FLT_MAX for a seedless column; the L1
 // sweeps yield the plain distance.  Both are integers < 2^24, so any exact method gives the
 // reference's bits.  One wave per column (k, x); lanes are 64 consecutive y.
-__device__ __forceinline__ int wave_scan_max_excl(int v, int lane) {  // exclusive prefix max
-    int incl = v;
-    for (int d = 1; d < kWave; d <<= 1) {
-        const int o = __shfl_up(incl, d);
-        if (lane >= d) incl = max(incl, o);
-    }
-    const int prev = __shfl_up(incl, 1);
-    return lane == 0 ? INT_MIN : prev;
-}
-__device__ __forceinline__ int wave_scan_min_excl_rev(int v, int lane) {  // exclusive suffix min
-    int incl = v;
-    for (int d = 1; d < kWave; d <<= 1) {
-        const int o = __shfl_down(incl, d);
-        if (lane + d < kWave) incl = min(incl, o);
-    }
-    const int nxt = __shfl_down(incl, 1);
-    return lane == kWave - 1 ? INT_MAX : nxt;
-}
-__device__ __forceinline__ int wave_max(int v) {
-    for (int d = 32; d >= 1; d >>= 1) v = max(v, __shfl_xor(v, d));
-    return v;
-}
-__device__ __forceinline__ int wave_min(int v) {
-    for (int d = 32; d >= 1; d >>= 1) v = min(v, __shfl_xor(v, d));
-    return v;
-}
-
-// Column-chunk descriptor: for column (k, x) and the 64 rows [64c, 64c+64): the seed bits of the
-// chunk, the last seed row before it and the first seed row after it.  16 bytes per 64 pixels,
-// stored [k][c][x] so that a wave sweeping along x prefetches 64 columns with one coalesced load.
-static constexpr int kFar = 1 << 30;  // "no seed on that side": a row 2^30 away (rows are < 2^14)
-struct __attribute__((aligned(16))) ColDesc {
-    unsigned long long word;
-    int prev;  // -kFar: none
-    int next;  // +kFar: none
-};
-// a column without any seed in the slice (all its chunks say the same)
-__device__ __forceinline__ bool desc_seedless(const uint4& d) {
-    return (d.x | d.y) == 0u && (int)d.z == -kFar && (int)d.w == kFar;
-}
-
 // The seed words are cleared as they are read (when one pass reads each word once), so the next build of
 // the same size starts from a zero bitmap without a separate fill.
 __global__ void __launch_bounds__(256) k_coldesc(unsigned long long* __restrict__ bitmap,
@@ -179,45 +139,6 @@ __global__ void __launch_bounds__(256) k_coldesc_tile(unsigned long long* __rest
             if (lane == 1 && half == 0 && x0 + 32 >= W) dst[1] = 0u;  // no block for the word's upper half
         }
     }
-}
-
-// Pass 1 of distanceTransform (imgproc.h:178 / :186, along y) evaluated on the fly.  On a
-// 0 / FLT_MAX image the lower-envelope pass yields exactly the squared distance to the nearest
-// seed of the column (every envelope owner is a seed and owns itself), or FLT_MAX for a seedless
-// column; the L1 sweeps yield the plain distance.  Both are integers < 2^24, so this bit-scan
-// gives the reference's bits.  y = 64c + lane.
-template <bool SQUARED>
-__device__ __forceinline__ float column_value(unsigned long long wc, int pc, int nc, int lane, int y) {
-    // branch-free: a missing neighbour chunk seed is a position 2^30 away (the descriptor says so), so "no seed
-    // in the column" is d >= 2^29 (rows are < 2^14)
-    const unsigned long long dnw = wc >> lane;         // bit 0 = own row, upwards = rows below it in the image
-    const unsigned long long upw = wc << (63 - lane);  // bit 63 = own row
-    const int d_dn = dnw ? __ffsll((long long)dnw) - 1 : nc - y;
-    const int d_up = upw ? __clzll(upw) : y - pc;
-    const int d = min(d_up, d_dn);
-    const float df = (float)d;
-    return d >= (1 << 29) ? FLT_MAX : (SQUARED ? df * df : df);  // d < 2^14: df * df is the exact integer
-}
-
-// The squared value for a SEEDED column whose descriptor fields are wave-uniform (read with v_readlane): most columns of
-// a chunk have no seed inside the chunk's 64 rows (a line crosses a chunk in a few columns), and then the value is the
-// distance to the neighbour seeds alone -- 5 vector instructions behind a scalar branch instead of ~22.  (A seeded
-// column has a seed in some chunk, so a missing side is 2^30 away and the other one decides: never FLT_MAX here.)
-__device__ __forceinline__ float column_value_sq_seeded(unsigned long long wc, int pc, int nc, int lane, int y) {
-    if (wc == 0ull) {
-        const int d = min(y - pc, nc - y);
-        const float df = (float)d;
-        return df * df;
-    }
-    return column_value<true>(wc, pc, nc, lane, y);
-}
-
-__device__ __forceinline__ void desc_lane(const ColDesc& d, int j, unsigned long long& wc, int& pc, int& nc) {
-    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(d.word & 0xffffffffull), j);
-    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(d.word >> 32), j);
-    wc = ((unsigned long long)hi << 32) | lo;
-    pc = __builtin_amdgcn_readlane(d.prev, j);
-    nc = __builtin_amdgcn_readlane(d.next, j);
 }
 
 // ------------------------------------------------------------------------------------------ K2
@@ -548,7 +469,6 @@ __global__ void __launch_bounds__(256) k_pass2_l2(const ColDesc* __restrict__ de
 //             imgproc.h:126-127), re-evaluated from the owner of pixel v found a few entries back
 //   k_fill    lane = (row, quarter of the pixels): pure fill from the owner list, entries staged through
 //             LDS in rounds of RE
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // store_unit_note: every 16-byte store of this file carries its whole offset in the lane (vector) offset, never in the
 // scalar offset operand.  A store of more than 8 bytes reads its data registers late, and a vector instruction that
 // overwrites them right behind it needs a wait state; the compiler inserts it only when the store has NO scalar
@@ -560,8 +480,6 @@ static constexpr int kFillParts = 4;
 
 // Row-major scratch: every lane streams through its own row's records (the positions differ from row to row, so a
 // [slot][row] layout would scatter the lanes of one access over as many pages as rows).
-struct EnvEntry { int v; float f; float z; };       // one stack entry (imgproc.h: v[k], f[v[k]], z[k])
-struct OwnEntry { unsigned pk; float b; };          // (first pixel << 16 | column), addend
 struct K2Buf {
     EnvEntry* ent;                        // envelope entries [row][slot], eslots per row
     OwnEntry* own;                        // owner list [row][index], lslots per row
@@ -577,19 +495,6 @@ struct K2Buf {
     int addend_waves;                     // waves of a block that share the addend pass (a power of two; 0 = all of them)
     const unsigned long long* colmask;    // [slice][(W + 63) / 64]: the slice's seeded columns (k_coldesc_tile), or null
 };
-
-__device__ __forceinline__ unsigned long long uni64(unsigned long long v) {
-    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
-    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
-    return ((unsigned long long)hi << 32) | lo;
-}
-__device__ __forceinline__ void desc_lane4(const uint4& d, int j, unsigned long long& wc, int& pc, int& nc) {
-    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)d.x, j);
-    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)d.y, j);
-    wc = ((unsigned long long)hi << 32) | lo;
-    pc = __builtin_amdgcn_readlane((int)d.z, j);
-    nc = __builtin_amdgcn_readlane((int)d.w, j);
-}
 
 // Phase 1 of k_sweep.  smask: seeded columns of the slice, 64 per word (W <= 16384); cj: junction column of
 // segment w per row; ring: stack entries below the top, (float(2 v), f[v], z, float(v)^2), C per thread.
@@ -940,8 +845,8 @@ __device__ __forceinline__ void addend_phase(int W, int S, int part_w, const K2B
                     unsigned hp0, hp1, hp2, hp3;
                     float hb0, hb1, hb2;
                     asm volatile("v_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %6\n\tv_mov_b32 %3, %7"
-                                 : "=v"(hp0), "=v"(hp1), "=v"(hp2), "=v"(hp3) : "v"(h0.pk), "v"(h1.pk), "v"(h2.pk), "v"(h3.pk));
-                    asm volatile("v_mov_b32 %0, %3\n\tv_mov_b32 %1, %4\n\tv_mov_b32 %2, %5" : "=v"(hb0), "=v"(hb1), "=v"(hb2) : "v"(h0.b), "v"(h1.b), "v"(h2.b));
+                                 : "=&v"(hp0), "=&v"(hp1), "=&v"(hp2), "=&v"(hp3) : "v"(h0.pk), "v"(h1.pk), "v"(h2.pk), "v"(h3.pk));
+                    asm volatile("v_mov_b32 %0, %3\n\tv_mov_b32 %1, %4\n\tv_mov_b32 %2, %5" : "=&v"(hb0), "=&v"(hb1), "=&v"(hb2) : "v"(h0.b), "v"(h1.b), "v"(h2.b));
                     if (DBG) { n_probe += 4; n_hbm += 4; }
                     const bool w1 = i1 >= lc - KL, w2 = i2 >= lc - KL, w3 = i3 >= lc - KL;  // (optr itself is behind the window here)
                     const unsigned pk0 = hp0, pk1 = w1 ? l_pk[i1 & (KL - 1)][lane] : hp1, pk2 = w2 ? l_pk[i2 & (KL - 1)][lane] : hp2,
@@ -1995,7 +1900,13 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after) {
             float* sz = sf + (size_t)W * nwaves * R;
             const int* gate = nullptr;
 #define FDCM_K2(RR, CC, SS, PP) hipLaunchKernelGGL((k_pass2_l2<RR, CC, SS, PP>), dim3(wblocks), dim3(256), 0, st, d_desc, vol, W, H, HW64, nwaves, sv, sf, sz, gate, segmented ? 1 : 0)
-            if (segmented) {
+            static const bool env_junction = getenv("FDCM_K2_JUNCTION") != nullptr;  // measurement: the junction-verified sweep at every size
+            if (segmented && kb.colmask && sweep_balanced_applies(W, H) && !env_junction) {
+                // every value of the pass is an exact integer: ranges of equal column count, merged (fdcm_sweep.hip)
+                SweepBuf sb{};
+                sb.ent = kb.ent; sb.own = kb.own; sb.order = kb.order; sb.cost = kb.cost; sb.eslots = kb.eslots; sb.lslots = kb.lslots; sb.colmask = kb.colmask;
+                launch_sweep_balanced(st, d_desc, vol, W, H, HW64, nchunks, sb);
+            } else if (segmented) {
                 // One launch: the phases' tails overlap between chunks (the three-launch form is kept for measurements:
                 // FDCM_K2_UNFUSED).  More than 4 segments (FDCM_K2_SEGMENTS): 512-thread blocks with an 8-entry ring.
                 const bool three = env_unfused;

@@ -1,0 +1,31 @@
+// fdcm_sweep.h -- the balanced L2 / L2^2 sweep (fdcm_sweep.hip), as run_build (fdcm_build.hip) sees it.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace fdcm {
+
+struct EnvEntry;
+struct OwnEntry;
+
+static constexpr int kSweepSegments = 8;  // column ranges per row = waves per workgroup
+
+// Scratch of the sweep, row-major (every lane streams through its own row's records).
+struct SweepBuf {
+    EnvEntry* ent;                        // stack entries [row][slot], eslots per row (>= W)
+    OwnEntry* own;                        // owner list [row][index], lslots per row (>= W + 2)
+    const int* order;                     // launch position -> chunk (longest chunks of the previous build first), or null
+    int* cost;                            // per chunk: 100 MHz ticks from the block's start to the end of its owner walk
+    int eslots, lslots;
+    const unsigned long long* colmask;    // [slice][(W + 63) / 64]: the slice's seeded columns (k_coldesc_tile)
+#ifdef FDCM_LAB
+    long long* lab;                       // lab builds (make LAB=1): 16 clock stamps / counters per (chunk, wave), or null
+#endif
+};
+
+// the sweep applies when every value of the pass is an exact integer (see fdcm_sweep.hip)
+inline bool sweep_balanced_applies(long W, long H) { return W * W + H * H <= (1L << 24); }
+
+// queues the sweep of nchunks (slice, 64-row chunk) pairs on st; vol receives the transforms in the interleaved layout
+void launch_sweep_balanced(hipStream_t st, const void* desc, float* vol, int W, int H, int HW64, long nchunks, const SweepBuf& B);
+
+}  // namespace fdcm

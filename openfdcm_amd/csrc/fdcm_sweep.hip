@@ -1,0 +1,652 @@
+// fdcm_sweep.hip -- the balanced L2 / L2^2 sweep: both 1-D passes of distanceTransform<float, L2 / L2_SQUARED>
+// (imgproc.h:91-130, :178-193) for feature sizes with W^2 + H^2 <= 2^24.
+//
+// What the reference's second pass computes, when every number in it is exact.  Pass 1 leaves integers: the squared
+// distance to the column's nearest seed (or FLT_MAX for a column without one, which never owns a pixel once any column
+// has a seed).  With W^2 + H^2 <= 2^24 every numerator (f[q] + q^2) - f[v] - v^2 of imgproc.h:111 is an exact integer,
+// every denominator 2 (q - v) <= 2 (W - 1) too, so the only rounded quantity is the quotient s = RN(N / D), and RN is
+// monotone.  Two facts follow (DESIGN.md section 4 has the proof; tools/sim/exact_owner_sim.cpp checks it against the
+// literal pass on the BASELINE scenes and on random / near-degenerate columns):
+//   (1) for an integer pixel q <= W - 1 < 2^12:  q <= RN(N / D)  <=>  q <= N / D   (q - N / D is 0 or at least 1 / D, far
+//       above half an ulp of q), so the fill's `while (z[k + 1] < q)` (:124) classifies pixels as exact arithmetic would;
+//   (2) the float construction pops at least what the exact one pops, and a vertex it pops in addition has an exact
+//       region narrower than an ulp: it owns no pixel.
+//   => the owner of every pixel in the reference's run is the EXACT owner: the seeded column u minimising
+//      f[u] + (q - u)^2 over the integers, the smallest u on a tie.  The same holds for the reference's construction run on
+//      ANY subset of the columns that contains those owners.
+// So a row may be cut anywhere: S waves run the literal construction on S column ranges of equal seeded-column count,
+// each on its own stack (bottom = its first column, z = -inf), and the stacks are then merged from left to right by
+// landing the next range's entries on the accumulated stack (pop while s <= z, as the reference would) until one of
+// them stays on its local predecessor -- which IS the reference's construction on the union of the local stacks, a set
+// that contains every pixel owner.  No junction search, no speculation, no redo; the longest wave of a block holds
+// n / S columns whatever the scene looks like.  The fill with the in-place read-back (:126-127) is unchanged:
+// the owner list (first pixel, column, addend) of a row, addend = f[v] or the already written g[v].
+//
+// One workgroup per (slice, 64-row chunk), kSeg waves, lane = row:
+//   local run   wave w: the literal construction over its columns; stack = top entry in registers + a ring of kRing
+//               entries per row in LDS + HBM scratch behind it (row-major); everything also lands in HBM for the walk
+//   merge       wave 0: per row, the junctions from left to right; entries come from the LDS rings (HBM behind them)
+//   owner walk  all waves, 64 / kSeg rows each: one walk over the merged stack of a row -> owner list
+//   fill        all waves, W / kSeg pixels each, 16-byte units of the interleaved layout [k][x/4][y][x%4]
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "fdcm_build_dev.h"
+#include "fdcm_quotient.h"
+#include "fdcm_sweep.h"
+
+namespace fdcm {
+
+static constexpr int kSeg = kSweepSegments;  // waves per block = column ranges per row = fill parts
+static constexpr int kNT = 64 * kSeg;
+static constexpr int kRing = 8;      // stack entries per (row, range) below the top kept in LDS
+static constexpr int kRE = 16;       // owner entries per row and round of the fill
+static constexpr int kMinCols = 16;  // a range holds at least this many seeded columns (fewer ranges on small slices)
+
+struct SweepLds {
+    unsigned long long smask[64];    // the slice's seeded columns, 64 per word (W <= 4096)
+    int t_cnt[kSeg][64];             // entries of the local stack of (range, row)
+    int t_base[kSeg][64];            // of which [t_base, t_cnt) are in the LDS ring (all of them are in HBM too)
+    int t_lo[kSeg][64], t_hi[kSeg][64];  // after the merge: the entries [t_lo, t_hi] of the local stack are on the row's stack
+    int t_prev[kSeg][64];            // the range below this one on the row's stack at the time it landed
+    int t_K[kSeg][64];               // the walk: stream index -> HBM slot offset of (range, row)
+    int s_slot0[kSeg];               // first HBM slot of a range's entries (its first column: ranges are disjoint)
+    int s_lcount[64];                // owner entries per row
+    int s_pi[kSeg][64];              // [p - 1][row]: list index that owns the first pixel of fill part p
+};
+
+// position of the t-th set bit (t from 0) of the mask words; wave-uniform
+__device__ __forceinline__ int select_column(const unsigned long long* smask, int t) {
+    int b = 0;
+    unsigned long long mk = uni64(smask[0]);
+    while (__popcll(mk) <= t) { t -= __popcll(mk); ++b; mk = uni64(smask[b]); }
+    for (; t > 0; --t) mk &= mk - 1ull;
+    return b * 64 + __ffsll((long long)mk) - 1;
+}
+
+// ---- the literal construction over the seeded columns [q0, ql] of the slice, bottom = q0 (imgproc.h:100-121)
+// ring entries: (float(2 v), f[v], z, float(v)^2)
+__device__ __forceinline__ void local_run(const uint4* __restrict__ dp, int W, const unsigned long long* smask, int q0, int ql, int lane,
+                                          int y, int tid, float4 (*ring)[kNT], EnvEntry* __restrict__ ent, int& cnt_out, int& base_out) {
+    const float inf = f_inf();
+    const uint4 db = dp[q0];
+    // top entry t and the entry below it u (a register copy of ring entry cnt - 1, so that a single pop needs no LDS round trip)
+    float tvf = (float)q0;
+    float tf = column_value_sq_seeded(((unsigned long long)db.y << 32) | db.x, (int)db.z, (int)db.w, lane, y);
+    float tz = -inf;
+    float tv2 = tvf * tvf, tvx2 = tvf + tvf;
+    float4 u = make_float4(0.f, 0.f, 0.f, 0.f);
+    int cnt = 0;   // entries below the top (indices 0..cnt-1); [base, cnt) in the LDS ring, [0, base) in HBM
+    int base = 0;
+    auto evict = [&]() {
+        const float4 e = ring[base & (kRing - 1)][tid];
+        ent[base] = EnvEntry{(int)e.x >> 1, e.y, e.z};
+        ++base;
+    };
+    const int qlo = q0 + 1, qhi = ql;
+    if (qlo <= qhi) {
+        const int wlo = qlo >> 6, whi = qhi >> 6;
+        for (int wd = wlo; wd <= whi; ++wd) {
+            // Lane j holds the descriptor of column 64 wd + j; a column's fields are read with v_readlane.  Loaded and waited
+            // for here, once per 64 columns, and not prefetched across words: a load still pending over the column loop makes
+            // the compiler wait for (nearly) all memory operations at every column, i.e. for the spill stores.
+            const uint4 dcur = dp[min(wd * 64 + lane, W - 1)];
+            asm volatile("; descriptors %0 %1 %2 %3 are complete here, before the column loop" ::"v"(dcur.x), "v"(dcur.y), "v"(dcur.z), "v"(dcur.w));
+            unsigned long long mk = uni64(smask[wd]);  // columns without a seed in the slice never own a pixel: skipped
+            if (wd == wlo) mk &= ~0ull << (qlo & 63);
+            if (wd == whi) mk &= ~0ull >> (63 - (qhi & 63));
+            while (mk) {
+                const int j = __ffsll((long long)mk) - 1;
+                mk &= mk - 1ull;
+                const int q = wd * 64 + j;
+                uint4 dq;
+                dq.x = (unsigned)__builtin_amdgcn_readlane((int)dcur.x, j);
+                dq.y = (unsigned)__builtin_amdgcn_readlane((int)dcur.y, j);
+                dq.z = (unsigned)__builtin_amdgcn_readlane((int)dcur.z, j);
+                dq.w = (unsigned)__builtin_amdgcn_readlane((int)dcur.w, j);
+                const float fq = column_value_sq_seeded(((unsigned long long)dq.y << 32) | dq.x, (int)dq.z, (int)dq.w, lane, y);
+                const float qf = (float)q;
+                const float q2 = qf * qf;  // rounds like the reference's float(long(q * q))
+                const float hq = fq + q2;
+                const float twoq = qf + qf;
+                float s;
+                unsigned long long any_pop;
+                // Test at the bottom: one taken branch per extra pass, none on the way out.  A lane that does not pop
+                // recomputes the same s in the passes other lanes still need.
+                do {
+                    // s = ((f[q] + q^2) - f[v] - v^2) / (2q - 2v), left to right in float (imgproc.h:111)
+                    const float N = (hq - tf) - tv2;
+                    s = envelope_quotient(N, twoq - tvx2);  // = N / (2q - 2v) bit for bit (fdcm_quotient.h)
+                    // pop while s <= z[k]: the bottom entry's z is -inf and s is finite, so the bottom is never popped
+                    const bool pop = s <= tz;
+                    any_pop = __builtin_amdgcn_ballot_w64(pop);
+                    if (pop) {
+                        tvx2 = u.x; tf = u.y; tz = u.z; tv2 = u.w;
+                        --cnt;
+                        if (cnt > 0) {
+                            if (__builtin_expect(cnt == base, 0)) {  // ring empty: up to four spilled entries come back together
+                                // all four are written (the ring is empty; entries below 0 land in free slots): no load stays pending
+                                const EnvEntry e0 = ent[max(base - 1, 0)], e1 = ent[max(base - 2, 0)], e2 = ent[max(base - 3, 0)], e3 = ent[max(base - 4, 0)];
+                                const float v0 = (float)e0.v, v1 = (float)e1.v, v2 = (float)e2.v, v3 = (float)e3.v;
+                                ring[(base - 1) & (kRing - 1)][tid] = make_float4(v0 + v0, e0.f, e0.z, v0 * v0);
+                                ring[(base - 2) & (kRing - 1)][tid] = make_float4(v1 + v1, e1.f, e1.z, v1 * v1);
+                                ring[(base - 3) & (kRing - 1)][tid] = make_float4(v2 + v2, e2.f, e2.z, v2 * v2);
+                                ring[(base - 4) & (kRing - 1)][tid] = make_float4(v3 + v3, e3.f, e3.z, v3 * v3);
+                                base = max(base - 4, 0);
+                            }
+                            u = ring[(cnt - 1) & (kRing - 1)][tid];  // needed at the next pop at the earliest
+                        }
+                    }
+                } while (any_pop != 0ull);
+                if (__builtin_expect(cnt - base == kRing, 0)) evict();
+                u = make_float4(tvx2, tf, tz, tv2);
+                ring[cnt & (kRing - 1)][tid] = u;
+                ++cnt;
+                tf = fq; tz = s; tv2 = q2; tvx2 = twoq;
+            }
+        }
+    }
+    // the top joins the entries; everything in the ring also goes to HBM (the ring keeps its content for the merge)
+    if (cnt - base == kRing) evict();
+    ring[cnt & (kRing - 1)][tid] = make_float4(tvx2, tf, tz, tv2);
+    ++cnt;
+#pragma unroll
+    for (int e = 0; e < kRing; ++e) {
+        const int i = base + e;
+        if (i < cnt) {
+            const float4 en = ring[i & (kRing - 1)][tid];
+            ent[i] = EnvEntry{(int)en.x >> 1, en.y, en.z};
+        }
+    }
+    cnt_out = cnt; base_out = base;
+}
+
+// ---- Phase 2 lane layout: wave j works on the rows 8 j .. 8 j + 7 of the chunk, lane = 8 g + t with g the row inside
+// the wave and t = 0..7.  The 8 lanes of a row hold the row's state in copies and spend their width on 8 stack entries
+// at a time: the rows of a chunk do the same thing at the same place (so splitting rows over lanes buys nothing), the
+// cost of a junction is the LONGEST landing among a wave's rows, and those have a heavy tail (entries popped on either
+// side per row and junction: p50 1, p90 10, p99 25 - 40: tools/sim/balanced_sim.cpp).
+static_assert(kSeg == 8, "phase 2 lays a wave out as 8 rows x 8 lanes");
+
+// first pixel above z: the entry takes over there (while (z[k+1] < q) ++k, imgproc.h:124): 0 below 0, W from W - 1 on
+__device__ __forceinline__ int first_pixel(float z, float Wf) { return (int)floorf(__builtin_fminf(__builtin_fmaxf(z, -1.f), Wf - 0.5f)) + 1; }
+
+// ---- merge of the ranges' stacks of a row, left to right: the reference's construction continued with the next range's
+// entries as the incoming columns.  An incoming entry is tested against the 8 entries at the top of the row's stack at
+// once (it pops the leading ones whose test says so: the reference stops at the first that does not), and the 8 entries
+// behind it against the entry it landed on at once (entry c + 1 pops entry c if its local z -- its quotient on c, the very
+// test the reference makes -- is <= c's quotient on the landing entry; landing deeper only raises that quotient, so what
+// this decides the reference decides too, and what it leaves open the next round settles).
+__device__ __forceinline__ void merge_bulk(SweepLds& L, int S, int row, int t, int sh, float4 (*ring)[kNT], EnvEntry* __restrict__ entr, long long* lab) {
+#ifdef FDCM_LAB
+    long long n_iter = 0, n_hbm = 0, n_refill = 0;
+#endif
+    // entry idx of (range seg, this row) as (2 v, f, z, v^2); from the LDS ring when it is still there, else from HBM
+    auto fetch = [&](int seg, int idx, int sbase, int sslot) -> float4 {
+        float4 e = ring[idx & (kRing - 1)][seg * 64 + row];
+        const bool hb = idx < sbase;
+        if (__builtin_amdgcn_ballot_w64(hb) != 0ull) {
+#ifdef FDCM_LAB
+            ++n_hbm;
+#endif
+            const EnvEntry h = entr[sslot + idx];
+            int hv; float hf, hz;
+            asm volatile("v_mov_b32 %0, %3\n\tv_mov_b32 %1, %4\n\tv_mov_b32 %2, %5" : "=&v"(hv), "=&v"(hf), "=&v"(hz) : "v"(h.v), "v"(h.f), "v"(h.z));
+            if (hb) { const float vf = (float)hv; e = make_float4(vf + vf, hf, hz, vf * vf); }
+        }
+        return e;
+    };
+    // The incoming entries of every junction are fetched together before the first one is needed (one trip to memory for
+    // all of them; the sets rotate through named registers): lane t holds the entries t and t + 8 of the range as
+    // (2 v, f + v^2, local z).
+    struct Cand { float a2v, ahq, az, b2v, bhq, bz; };
+    auto load_cand = [&](int w, int cb) -> Cand {
+        Cand c{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (w < S) {
+            const int nw = L.t_cnt[w][row], ws = L.s_slot0[w];
+            const EnvEntry ea = entr[ws + min(cb + t, nw - 1)], eb = entr[ws + min(cb + t + 8, nw - 1)];
+            const float av = (float)ea.v, bv = (float)eb.v;
+            c.a2v = av + av; c.ahq = ea.f + av * av; c.az = ea.z;
+            c.b2v = bv + bv; c.bhq = eb.f + bv * bv; c.bz = eb.z;
+        }
+        return c;
+    };
+    Cand c0 = load_cand(1, 0), c1 = load_cand(2, 0), c2 = load_cand(3, 0), c3 = load_cand(4, 0), c4 = load_cand(5, 0), c5 = load_cand(6, 0), c6 = load_cand(7, 0);
+    int ms = 0, mi = L.t_cnt[0][row] - 1, ms_lo = 0, ms_base = L.t_base[0][row], ms_slot = L.s_slot0[0];  // the top of the row's stack
+    L.t_lo[0][row] = 0;
+#pragma unroll 1
+    for (int w = 1; w < S; ++w) {
+        const int nw = L.t_cnt[w][row], wbase = L.t_base[w][row], wslot = L.s_slot0[w];
+        // window of 16 incoming entries starting at entry cb: lane t holds cb + t (A) and cb + t + 8 (B)
+        float A2v = c0.a2v, Ahq = c0.ahq, Az = c0.az, B2v = c0.b2v, Bhq = c0.bhq, Bz = c0.bz;
+        c0 = c1; c1 = c2; c2 = c3; c3 = c4; c4 = c5; c5 = c6;
+        int cur = 0, cb = 0;
+        bool done = false;
+        float zc = 0.f;
+        for (;;) {
+#ifdef FDCM_LAB
+            ++n_iter;
+#endif
+            // ---- the incoming entry cur against the 8 entries at the top of the row's stack
+            const int ci = cur - cb;  // window index, 0..8
+            const int csrc = sh + (ci & 7);
+            const float cA2v = __shfl(A2v, csrc), cAhq = __shfl(Ahq, csrc), cB2v = __shfl(B2v, csrc), cBhq = __shfl(Bhq, csrc);
+            const float c2v = ci < 8 ? cA2v : cB2v, chq = ci < 8 ? cAhq : cBhq;
+            const int idx = mi - t;
+            const bool valid = idx >= ms_lo;
+            const float4 e = fetch(ms, max(idx, ms_lo), ms_base, ms_slot);
+            // s = ((f[q] + q^2) - f[v] - v^2) / (2q - 2v), left to right in float (imgproc.h:111); pop while s <= z[k]
+            const float s = envelope_quotient((chq - e.y) - e.w, c2v - e.x);
+            const bool pop = valid && s <= e.z;
+            const unsigned m8 = (unsigned)(__builtin_amdgcn_ballot_w64(pop) >> sh) & 0xffu;
+            const int npop = __builtin_ctz(~m8);  // leading pops, 0..8
+            const int nvalid = min(8, mi - ms_lo + 1);
+            bool landed = false;
+            if (!done) {
+                if (npop >= nvalid) {  // everything in sight is gone (the row's first entry has z = -inf: it never pops)
+                    if (mi - 8 >= ms_lo) mi -= 8;
+                    else {  // the whole range: on to the range below it
+                        L.t_hi[ms][row] = ms_lo - 1;
+                        ms = L.t_prev[ms][row];
+                        ms_lo = L.t_lo[ms][row]; ms_base = L.t_base[ms][row]; ms_slot = L.s_slot0[ms];
+                        mi = L.t_hi[ms][row];
+                    }
+                } else { mi -= npop; landed = true; }
+            }
+            // the entry landed on (lane npop looked at it) and the quotient of that test
+            const int lsrc = sh + min(npop, 7);
+            const float l2v = __shfl(e.x, lsrc), lf = __shfl(e.y, lsrc), lv2 = __shfl(e.w, lsrc), ls = __shfl(s, lsrc);
+            if (landed) zc = ls;
+            // ---- the entries behind it: entry cur + t + 1 pops entry cur + t if its local z <= the latter's quotient on the landing entry
+            const int wi = ci + t, wn = wi + 1;  // window indices of the entry and of its successor (<= 16)
+            const int ksrc = sh + (wi & 7), nsrc = sh + (wn & 7);
+            const float kA2v = __shfl(A2v, ksrc), kAhq = __shfl(Ahq, ksrc), kB2v = __shfl(B2v, ksrc), kBhq = __shfl(Bhq, ksrc);
+            const float nAz = __shfl(Az, nsrc), nBz = __shfl(Bz, nsrc);
+            const float k2v = wi < 8 ? kA2v : kB2v, khq = wi < 8 ? kAhq : kBhq, nz = wn < 8 ? nAz : nBz;
+            const float sk = t == 0 ? ls : envelope_quotient((khq - lf) - lv2, k2v - l2v);
+            const bool adv = landed && cur + t + 1 < nw && wn <= 15 && nz <= sk;
+            const unsigned a8 = (unsigned)(__builtin_amdgcn_ballot_w64(adv) >> sh) & 0xffu;
+            const int nadv = __builtin_ctz(~a8);
+            if (landed) {
+                if (nadv == 0) done = true;
+                else cur += nadv;
+            }
+            // the window ran out (more than 8 incoming entries gone): the next 16 from memory
+            if (__builtin_amdgcn_ballot_w64(!done && cur - cb >= 8) != 0ull) {
+#ifdef FDCM_LAB
+                ++n_refill;
+#endif
+                if (!done && cur - cb >= 8) cb = cur;
+                const Cand c = load_cand(w, cb);
+                A2v = c.a2v; Ahq = c.ahq; Az = c.az; B2v = c.b2v; Bhq = c.bhq; Bz = c.bz;
+            }
+            if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;
+        }
+        L.t_hi[ms][row] = mi;
+        L.t_prev[w][row] = ms;
+        L.t_lo[w][row] = cur;
+        if (cur >= wbase) ring[cur & (kRing - 1)][w * 64 + row].z = zc;
+        entr[wslot + cur].z = zc;
+        ms = w; mi = nw - 1; ms_lo = cur; ms_base = wbase; ms_slot = wslot;
+    }
+    L.t_hi[ms][row] = mi;
+#ifdef FDCM_LAB
+    if (lab && (threadIdx.x & 63) == 0) { lab[12] = n_iter; lab[13] = n_hbm; lab[14] = n_refill; }
+#endif
+}
+
+// ---- the walk over the merged stack of a row -> owner list (first pixel, column, addend).  The stack of a row is the valid
+// parts of its ranges' stacks back to back.  8 entries of a row per step, one per lane: first pixels, ownership and list
+// positions are independent per entry; the addend of an entry that takes over behind its own column is the value the
+// reference reads back at its column, g[v] = addend_o + (v - v_o)^2 with o the owner of pixel v (imgproc.h:126-127) -- a
+// chain through earlier entries.  Every term is an integer below 2^24, so the chain inside a step is summed by pointer
+// doubling (3 rounds for 8 entries) instead of entry by entry; the regrouping changes no bit.
+constexpr int kWin = 64;        // owner entries per row kept in LDS for the look-ups
+constexpr int kWinStride = 65;  // (odd: the lanes of a row read neighbouring list positions)
+__device__ __forceinline__ void walk_batched(SweepLds& L, int W, int S, int part_w, const SweepBuf& B, long chunk, int row, int t, int sh,
+                                             unsigned (*l_pk)[kWinStride], float (*l_b)[kWinStride], int (*l_pt)[kWinStride]) {
+    const size_t r = (size_t)chunk * 64 + row;
+    OwnEntry* own = B.own + r * (size_t)B.lslots;
+    const EnvEntry* ent = B.ent + r * (size_t)B.eslots;
+    // Range table of the row: stream index i lies in range w for i in [o_w, o_{w+1}), at slot i + K_w.
+    // (K lives in LDS: the compiler turns a select chain over a register array into an indexed load from scratch memory)
+    int o[kSeg + 1];
+    o[0] = 0;
+#pragma unroll
+    for (int w = 0; w < kSeg; ++w) {
+        const int lo = w < S ? L.t_lo[w][row] : 0, n = w < S ? max(L.t_hi[w][row] - lo + 1, 0) : 0;
+        o[w + 1] = o[w] + n;
+        L.t_K[w][row] = (w < S ? L.s_slot0[w] : 0) + lo - o[w];  // (every lane of a row writes the same value)
+    }
+    const int total = o[kSeg];
+    auto slot_of = [&](int i) {
+        int w = 0;
+#pragma unroll
+        for (int j = 1; j < kSeg; ++j) w += i >= o[j] ? 1 : 0;  // the last range that starts at or before i (empty ranges in between start there too)
+        return i + L.t_K[w][row];
+    };
+    auto load = [&](int i) -> EnvEntry { return ent[slot_of(min(i, total - 1))]; };
+    const float Wf = (float)W;
+    int lc = 0;    // owner entries of the row so far
+    int optr = 0;  // list index of the owner of the column looked up last (columns only grow, so do the owners)
+    const int tmax = __builtin_amdgcn_readfirstlane(wave_max(total));
+    EnvEntry en = load(t), nx = load(8 + t);
+    for (int i0 = 0; i0 < tmax; i0 += 8) {
+        const EnvEntry e = en;
+        en = nx;
+        nx = load(i0 + 16 + t);  // in flight during the next step
+        const int i = i0 + t;
+        const bool valid = i < total;
+        // z of the entry behind: the next lane's, the next step's first for the last lane
+        const float zn_in = __shfl(e.z, sh + min(t + 1, 7)), zn_nx = __shfl(en.z, sh);
+        const float zn = t < 7 ? zn_in : zn_nx;
+        const int st = first_pixel(e.z, Wf), stn = i + 1 < total ? first_pixel(zn, Wf) : W;
+        const bool owns = valid && st < stn;  // owner of q = the last entry with z < q (imgproc.h:124): the pixels [st, stn)
+        const unsigned m8 = (unsigned)(__builtin_amdgcn_ballot_w64(owns) >> sh) & 0xffu;
+        const int pos = lc + __popc(m8 & ((1u << t) - 1u));
+        const int lc_new = lc + __popc(m8);
+        const int win_lo = lc_new - kWin;  // list positions from here on are in the LDS window
+        const bool quirk = owns && st > e.v;  // takes over behind its own column: the addend is the value already written at e.v
+        const unsigned pk = ((unsigned)st << 16) | (unsigned)e.v;
+        if (owns) l_pk[row][pos & (kWin - 1)] = pk;
+        auto list_pk = [&](int j, bool need) -> unsigned {
+            unsigned v = l_pk[row][j & (kWin - 1)];
+            if (__builtin_amdgcn_ballot_w64(need && j < win_lo) != 0ull) {  // older than the window (rare): from the list in HBM, consumed in place
+                const unsigned a0 = own[max(j, 0)].pk;
+                unsigned hv;
+                asm volatile("v_mov_b32 %0, %1" : "=v"(hv) : "v"(a0));
+                if (j < win_lo) v = hv;
+            }
+            return v;
+        };
+        // the owner of pixel e.v: the last list entry whose first pixel is <= e.v, between the previous look-up's answer and pos - 1
+        int plo = optr, phi = pos - 1;
+        while (__builtin_amdgcn_ballot_w64(quirk && plo < phi) != 0ull) {
+            const bool act = quirk && plo < phi;
+            const int mid = (plo + phi + 1) >> 1;
+            const unsigned mpk = list_pk(mid, act);
+            if (act) { if ((int)(mpk >> 16) <= e.v) plo = mid; else phi = mid - 1; }
+        }
+        float bval = e.f;
+        int ptr = -1;
+        if (__builtin_amdgcn_ballot_w64(quirk) != 0ull) {
+            const unsigned ppk = list_pk(plo, quirk);
+            float pb = l_b[row][plo & (kWin - 1)];
+            if (__builtin_amdgcn_ballot_w64(quirk && plo < win_lo) != 0ull) {
+                const float a0 = own[max(plo, 0)].b;
+                float hb;
+                asm volatile("v_mov_b32 %0, %1" : "=v"(hb) : "v"(a0));
+                if (plo < win_lo) pb = hb;
+            }
+            if (quirk) {
+                const float dv = (float)(e.v - (int)(ppk & 0xffffu));  // dv * dv rounds like float(long(dv * dv))
+                bval = dv * dv;
+                if (plo < lc) bval = pb + bval;  // an entry of an earlier step: final
+                else ptr = plo;                  // an entry of this step: summed below
+            }
+        }
+        if (owns) { l_b[row][pos & (kWin - 1)] = bval; l_pt[row][pos & (kWin - 1)] = ptr; }
+        // pointer doubling inside the step: b_i = val_i + b_{ptr_i}; all lanes read before any lane writes
+#pragma unroll 1
+        for (int rd = 0; rd < 3; ++rd) {
+            if (__builtin_amdgcn_ballot_w64(ptr >= 0) == 0ull) break;
+            const bool act = ptr >= 0;
+            const float pb = l_b[row][ptr & (kWin - 1)];
+            const int pp = l_pt[row][ptr & (kWin - 1)];
+            asm volatile("; the reads of round %0 are complete before its writes" ::"v"(pb), "v"(pp));
+            if (act) { bval += pb; ptr = pp; l_b[row][pos & (kWin - 1)] = bval; l_pt[row][pos & (kWin - 1)] = ptr; }
+        }
+        if (owns) own[pos] = OwnEntry{pk, bval};
+        // the owner of the first pixel of a fill part
+        {
+            const int lo_st = __builtin_amdgcn_readfirstlane(wave_min(owns ? st : 0x7fffffff)), hi_st = __builtin_amdgcn_readfirstlane(wave_max(owns ? stn : -1));
+            for (int p = max(1, (lo_st + part_w - 1) / part_w); p < kSeg && p * part_w < hi_st; ++p) {
+                const int x = p * part_w;
+                if (owns && st <= x && x < stn) L.s_pi[p - 1][row] = pos;
+            }
+        }
+        // the next step's look-ups start at the owner found for the last entry of this one that looked
+        const unsigned q8 = (unsigned)(__builtin_amdgcn_ballot_w64(quirk) >> sh) & 0xffu;
+        const int qtop = q8 ? 31 - __builtin_clz(q8) : 0;
+        const int po = __shfl(plo, sh + qtop);
+        if (q8) optr = po;
+        lc = lc_new;
+    }
+    L.s_lcount[row] = lc;
+}
+
+// ---- pure fill (imgproc.h:122-128) from the owner list; wave p of a block fills the pixels
+// [p * part_w, (p + 1) * part_w) of the block's 64 rows
+__device__ __forceinline__ void fill_part(SweepLds& L, float* __restrict__ vol, int W, int H, long k, int c, long chunk, int part_w, const SweepBuf& B, int p,
+                                          unsigned (*f_pk)[kNT], float (*f_b)[kNT]) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int y = c * 64 + lane;
+    const size_t r = (size_t)chunk * 64 + lane;
+    int qcur = p * part_w;
+    const int qend = min(qcur + part_w, W);
+    if (qcur >= qend) return;  // (last phase of the kernel: nothing waits for this wave any more)
+    int idx = p == 0 ? 0 : L.s_pi[p - 1][lane];
+    const int lc = L.s_lcount[lane];
+    const OwnEntry* own = B.own + r * (size_t)B.lslots;
+    // The fill writes the interleaved layout (ivol_index: 16 bytes = 4 neighbouring columns of one row) that the
+    // propagation reads: a lane collects the values of a group of 4 columns and stores them as one unit, 64 rows = 1 KB
+    // contiguous per wave.  Parts start on a group (part_w is a multiple of 4).
+    const size_t sl = ivol_slice_floats(W, H);
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc(vol + (size_t)k * sl, 0, (unsigned)(sl * 4), 0x00020000);
+    const unsigned vrow = y < H ? (unsigned)y * 16u : 0x80000000u;  // rows past the image: dropped stores
+    const int grpB = H * 16;
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f;  // the group being collected (shift register: the newest value in g3)
+    while (qcur < qend) {
+        // entries [idx, idx + kRE) of every row go to LDS; the round ends where the first row would need entry idx + kRE
+        unsigned pk[kRE];
+        float bb[kRE];
+#pragma unroll
+        for (int e = 0; e < kRE; ++e) {
+            const OwnEntry oe = own[min(idx + e, lc - 1)];
+            pk[e] = oe.pk; bb[e] = oe.b;
+        }
+#pragma unroll
+        for (int e = 0; e < kRE; ++e) {
+            if (idx + e >= lc) pk[e] = 0x7fff0000u;  // past the list: never taken over
+            f_pk[e][tid] = pk[e]; f_b[e][tid] = bb[e];
+        }
+        const int lim = (int)(pk[kRE - 1] >> 16);
+        // (max: the lists the walk writes always allow progress; never spin on anything else)
+        const int qstop = max(qcur + 1, min(qend, __builtin_amdgcn_readfirstlane(wave_min(lim))));
+        unsigned cpk = pk[0], npk = pk[1];
+        float cb = bb[0], nb = bb[1];
+        int a = 0;
+        for (int q = qcur; q < qstop; ++q) {
+            const bool adv = q >= (int)(npk >> 16);
+            if (adv) { cpk = npk; cb = nb; ++a; }
+            npk = f_pk[a + 1][tid]; nb = f_b[a + 1][tid];  // a + 1 <= kRE - 1 because q < lim
+            const float dq = (float)(q - (int)(cpk & 0xffffu));  // dq * dq rounds like float(long(dq * dq))
+            g0 = g1; g1 = g2; g2 = g3; g3 = cb + dq * dq;
+            if ((q & 3) == 3) {  // wave-uniform
+                u32x4 out;
+                out.x = __float_as_uint(g0); out.y = __float_as_uint(g1); out.z = __float_as_uint(g2); out.w = __float_as_uint(g3);
+                // (the whole offset in the lane offset, none in the scalar operand: a 16-byte store reads its data late, and the
+                // compiler only inserts the wait state before the registers are overwritten when there is no scalar offset)
+                __builtin_amdgcn_raw_buffer_store_b128(out, rs, vrow + (unsigned)((q >> 2) * grpB), 0, 0);
+            }
+        }
+        idx += a;
+        qcur = qstop;
+    }
+    if (qend == W && (W & 3)) {  // the row's last group is partial: its columns past W are padding and hold 0
+        for (int q = W; q & 3; ++q) { g0 = g1; g1 = g2; g2 = g3; g3 = 0.f; }
+        u32x4 out;
+        out.x = __float_as_uint(g0); out.y = __float_as_uint(g1); out.z = __float_as_uint(g2); out.w = __float_as_uint(g3);
+        __builtin_amdgcn_raw_buffer_store_b128(out, rs, vrow + (unsigned)((W >> 2) * grpB), 0, 0);
+    }
+}
+
+__global__ void __launch_bounds__(kNT) k_sweep_balanced(const ColDesc* __restrict__ desc, float* __restrict__ vol, int W, int H, int HW64, int part_w,
+                                                        SweepBuf B) {
+    // one LDS pool for the phases: the construction's rings (kept through the merge), the walk's lists, the fill's staging
+    constexpr size_t kPoolBytes = std::max({(size_t)kRing * kNT * sizeof(float4), (size_t)3 * 64 * kWinStride * 4, (size_t)2 * kRE * kNT * 4});
+    __shared__ SweepLds L;
+    __shared__ float4 pool[kPoolBytes / sizeof(float4)];
+    const long long t_start = wall_clock64();
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long chunk = B.order ? B.order[blockIdx.x] : (long)blockIdx.x;
+#ifdef FDCM_LAB
+    long long* lab = B.lab ? B.lab + ((size_t)chunk * kSeg + wave) * 16 : nullptr;
+#define LAB_STAMP(i) do { if (lab && lane == 0) lab[i] = wall_clock64(); } while (0)
+#else
+#define LAB_STAMP(i) do { } while (0)
+#endif
+    LAB_STAMP(0);
+    const long k = chunk / HW64;
+    const int c = (int)(chunk - k * HW64);
+    const int y = c * 64 + lane;
+    const size_t r = (size_t)chunk * 64 + lane;
+    const uint4* dp = reinterpret_cast<const uint4*>(desc + ((size_t)k * HW64 + c) * W);
+    const int nwords = (W + 63) >> 6;
+    for (int b = tid; b < nwords; b += kNT) L.smask[b] = B.colmask[(size_t)k * nwords + b];
+    __syncthreads();
+    int n = 0;
+    for (int b = 0; b < nwords; ++b) n += __popcll(uni64(L.smask[b]));
+    if (n == 0) {
+        // no seed in the slice: column 0 owns every pixel with f = FLT_MAX, and FLT_MAX + d^2 == FLT_MAX (imgproc.h:127)
+        const size_t sl = ivol_slice_floats(W, H);
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(vol + (size_t)k * sl, 0, (unsigned)(sl * 4), 0x00020000);
+        const unsigned vrow = y < H ? (unsigned)y * 16u : 0x80000000u;
+        const int ngroups = (W + 3) >> 2;
+        for (int g = wave; g < ngroups; g += kSeg) {
+            u32x4 out;
+            out.x = __float_as_uint(FLT_MAX);
+            out.y = 4 * g + 1 < W ? __float_as_uint(FLT_MAX) : 0u;
+            out.z = 4 * g + 2 < W ? __float_as_uint(FLT_MAX) : 0u;
+            out.w = 4 * g + 3 < W ? __float_as_uint(FLT_MAX) : 0u;
+            __builtin_amdgcn_raw_buffer_store_b128(out, rs, vrow + (unsigned)(g * (H * 16)), 0, 0);
+        }
+        if (tid == 0) B.cost[chunk] = (int)(wall_clock64() - t_start);
+        return;
+    }
+    const int S = min(kSeg, max(1, n / kMinCols));  // ranges of this slice
+    float4(*ring)[kNT] = reinterpret_cast<float4(*)[kNT]>(pool);
+    if (wave < S) {
+        const int j0 = (int)(((long)n * wave) / S), j1 = (int)(((long)n * (wave + 1)) / S);  // ranks of the range's columns: [j0, j1), never empty
+        const int q0 = select_column(L.smask, j0), ql = select_column(L.smask, j1 - 1);
+        int cnt, base;
+        local_run(dp, W, L.smask, q0, ql, lane, y, tid, ring, B.ent + r * (size_t)B.eslots + q0, cnt, base);
+        L.t_cnt[wave][lane] = cnt; L.t_base[wave][lane] = base;
+        if (lane == 0) L.s_slot0[wave] = q0;
+#ifdef FDCM_LAB
+        if (lab) { const int mc = wave_max(cnt); if (lane == 0) { lab[8] = ql - q0 + 1; lab[9] = j1 - j0; lab[10] = mc; } }
+#endif
+    }
+    LAB_STAMP(1);
+    __syncthreads();  // every range's stack is in memory, its top entries in the rings
+    LAB_STAMP(2);
+    const int g8 = lane >> 3, t8 = lane & 7, sh8 = lane & 56, row8 = wave * 8 + g8;
+    {
+        EnvEntry* entr = B.ent + ((size_t)chunk * 64 + row8) * (size_t)B.eslots;
+#ifdef FDCM_LAB
+        merge_bulk(L, S, row8, t8, sh8, ring, entr, lab);
+#else
+        merge_bulk(L, S, row8, t8, sh8, ring, entr, nullptr);
+#endif
+    }
+    LAB_STAMP(3);
+    __syncthreads();  // every wave is through with the rings: their LDS becomes the walk's lists
+    LAB_STAMP(4);
+    {
+        unsigned* w32 = reinterpret_cast<unsigned*>(pool);
+        walk_batched(L, W, S, part_w, B, chunk, row8, t8, sh8, reinterpret_cast<unsigned(*)[kWinStride]>(w32),
+                     reinterpret_cast<float(*)[kWinStride]>(w32 + 64 * kWinStride), reinterpret_cast<int(*)[kWinStride]>(w32 + 2 * 64 * kWinStride));
+    }
+    LAB_STAMP(5);
+    __syncthreads();  // the chunk's owner lists are in memory
+    LAB_STAMP(6);
+    if (tid == 0) B.cost[chunk] = (int)(wall_clock64() - t_start);
+    {
+        unsigned* w32 = reinterpret_cast<unsigned*>(pool);
+        fill_part(L, vol, W, H, k, c, chunk, part_w, B, wave, reinterpret_cast<unsigned(*)[kNT]>(w32), reinterpret_cast<float(*)[kNT]>(w32 + kRE * kNT));
+    }
+    LAB_STAMP(7);
+#ifdef FDCM_LAB
+    if (lab && lane == 0) { lab[11] = L.s_lcount[wave * (64 / kSeg)]; }
+#endif
+#undef LAB_STAMP
+}
+
+void launch_sweep_balanced(hipStream_t st, const void* desc, float* vol, int W, int H, int HW64, long nchunks, const SweepBuf& B) {
+    const int part_w = (((W + kSeg - 1) / kSeg) + 3) & ~3;  // fill parts start on a group of 4 columns
+#ifdef FDCM_LAB
+    if (getenv("FDCM_SWEEP_LAB")) {  // per-wave phase times (100 MHz clock) and counters of this launch, on stderr
+        static DevBuf labbuf;
+        const size_t nl = (size_t)nchunks * kSeg * 16;
+        labbuf.reserve(nl * 8);
+        FDCM_HIP(hipMemsetAsync(labbuf.p, 0, nl * 8, st));
+        SweepBuf B2 = B;
+        B2.lab = labbuf.as<long long>();
+        hipLaunchKernelGGL(k_sweep_balanced, dim3((unsigned)nchunks), dim3(kNT), 0, st, (const ColDesc*)desc, vol, W, H, HW64, part_w, B2);
+        FDCM_HIP(hipStreamSynchronize(st));
+        std::vector<long long> d(nl);
+        FDCM_HIP(hipMemcpy(d.data(), labbuf.p, nl * 8, hipMemcpyDeviceToHost));
+        long long t0 = 0x7fffffffffffffffll, t1 = 0;
+        for (long ch = 0; ch < nchunks; ++ch) for (int w = 0; w < kSeg; ++w) { const long long* e = &d[((size_t)ch * kSeg + w) * 16]; if (e[0]) { t0 = std::min(t0, e[0]); t1 = std::max(t1, e[7]); } }
+        auto pct = [](std::vector<double>& v, double q) { if (v.empty()) return 0.0; std::sort(v.begin(), v.end()); return v[(size_t)(q * (v.size() - 1))]; };
+        const char* names[7] = {"local run", "wait 1", "merge", "wait 2", "owner walk", "wait 3", "fill"};
+        fprintf(stderr, "[sweep lab] %ld chunks, kernel span %.1f us (first stamp to last)\n", nchunks, (t1 - t0) / 100.0);
+        for (int ph = 0; ph < 7; ++ph) {
+            std::vector<double> v;
+            for (long ch = 0; ch < nchunks; ++ch) for (int w = 0; w < kSeg; ++w) {
+                const long long* e = &d[((size_t)ch * kSeg + w) * 16];
+                if (!e[0]) continue;
+                v.push_back((e[ph + 1] - e[ph]) / 100.0);
+            }
+            double sum = 0; for (double x : v) sum += x;
+            fprintf(stderr, "[sweep lab] %-16s us per wave: mean %7.1f  p50 %7.1f  p90 %7.1f  p99 %7.1f  max %7.1f\n", names[ph], v.empty() ? 0.0 : sum / v.size(), pct(v, .5), pct(v, .9), pct(v, .99), pct(v, 1.0));
+        }
+        {
+            std::vector<double> life, start, cols, it, hb, lst;
+            for (long ch = 0; ch < nchunks; ++ch) {
+                const long long* e = &d[(size_t)ch * kSeg * 16];
+                if (!e[0]) continue;
+                long long end = 0;
+                for (int w = 0; w < kSeg; ++w) end = std::max(end, d[((size_t)ch * kSeg + w) * 16 + 7]);
+                life.push_back((end - e[0]) / 100.0); start.push_back((e[0] - t0) / 100.0);
+                it.push_back((double)e[12]); hb.push_back((double)e[13]);
+                for (int w = 0; w < kSeg; ++w) { cols.push_back((double)d[((size_t)ch * kSeg + w) * 16 + 9]); lst.push_back((double)d[((size_t)ch * kSeg + w) * 16 + 10]); }
+            }
+            double ls = 0; for (double x : life) ls += x;
+            fprintf(stderr, "[sweep lab] block life us: mean %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f (sum %.0f); block start us: p50 %.1f p90 %.1f max %.1f\n", ls / life.size(), pct(life, .5), pct(life, .9),
+                    pct(life, .99), pct(life, 1.0), ls, pct(start, .5), pct(start, .9), pct(start, 1.0));
+            {  // the blocks that end last: where their time went (per phase: the longest wave)
+                std::vector<std::pair<double, long>> ends;
+                for (long ch = 0; ch < nchunks; ++ch) {
+                    long long end = 0;
+                    for (int w = 0; w < kSeg; ++w) end = std::max(end, d[((size_t)ch * kSeg + w) * 16 + 7]);
+                    if (d[(size_t)ch * kSeg * 16]) ends.push_back({(end - t0) / 100.0, ch});
+                }
+                std::sort(ends.begin(), ends.end());
+                for (size_t i = ends.size() > 6 ? ends.size() - 6 : 0; i < ends.size(); ++i) {
+                    const long ch = ends[i].second;
+                    double ph[7] = {0, 0, 0, 0, 0, 0, 0}, st0 = 1e30;
+                    long long cols = 0, depth = 0, iters = 0, hbm = 0, refill = 0, owners = 0;
+                    for (int w = 0; w < kSeg; ++w) {
+                        const long long* e = &d[((size_t)ch * kSeg + w) * 16];
+                        st0 = std::min(st0, (e[0] - t0) / 100.0);
+                        for (int q = 0; q < 7; ++q) ph[q] = std::max(ph[q], (e[q + 1] - e[q]) / 100.0);
+                        cols = std::max(cols, e[9]); depth = std::max(depth, e[10]); iters = std::max(iters, e[12]); hbm = std::max(hbm, e[13]); refill = std::max(refill, e[14]);
+                        owners = std::max(owners, e[11]);
+                    }
+                    fprintf(stderr, "[sweep lab] late block %ld (slice %ld chunk %ld): %.1f -> %.1f us | local %.1f merge %.1f walk %.1f fill %.1f | columns %lld deepest %lld merge steps %lld (hbm %lld, refills %lld) owners %lld\n",
+                            ch, ch / HW64, ch % HW64, st0, ends[i].first, ph[0], ph[2], ph[4], ph[6], cols, depth, iters, hbm, refill, owners);
+                }
+            }
+            fprintf(stderr, "[sweep lab] columns per wave p50 %.0f max %.0f; deepest local stack p50 %.0f p99 %.0f max %.0f; merge iterations per block p50 %.0f p90 %.0f max %.0f, with an HBM fetch p50 %.0f p90 %.0f max %.0f\n",
+                    pct(cols, .5), pct(cols, 1.0), pct(lst, .5), pct(lst, .99), pct(lst, 1.0), pct(it, .5), pct(it, .9), pct(it, 1.0), pct(hb, .5), pct(hb, .9), pct(hb, 1.0));
+        }
+        return;
+    }
+#endif
+    hipLaunchKernelGGL(k_sweep_balanced, dim3((unsigned)nchunks), dim3(kNT), 0, st, (const ColDesc*)desc, vol, W, H, HW64, part_w, B);
+}
+
+}  // namespace fdcm
