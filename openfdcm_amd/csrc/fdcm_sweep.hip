@@ -160,6 +160,21 @@ __device__ __forceinline__ void local_run(const uint4* __restrict__ dp, int W, c
             ent[i] = EnvEntry{(int)en.x >> 1, en.y, en.z};
         }
     }
+    // The merge looks at the 8 entries below a range's top first.  After a run of pops the ring holds fewer than that (it is
+    // only refilled when empty): the missing ones come back from HBM now, all lanes and entries in one trip, instead of one
+    // trip per junction later.
+    {
+        const int want = max(cnt - kRing, 0);
+        if (__builtin_amdgcn_ballot_w64(base > want) != 0ull) {
+            EnvEntry t0 = ent[max(base - 1, 0)], t1 = ent[max(base - 2, 0)], t2 = ent[max(base - 3, 0)], t3 = ent[max(base - 4, 0)],
+                     t4 = ent[max(base - 5, 0)], t5 = ent[max(base - 6, 0)], t6 = ent[max(base - 7, 0)];
+            auto put = [&](const EnvEntry& e, int idx) {
+                if (idx >= want) { const float vf = (float)e.v; ring[idx & (kRing - 1)][tid] = make_float4(vf + vf, e.f, e.z, vf * vf); }
+            };
+            put(t0, base - 1); put(t1, base - 2); put(t2, base - 3); put(t3, base - 4); put(t4, base - 5); put(t5, base - 6); put(t6, base - 7);
+            base = min(base, want);
+        }
+    }
     cnt_out = cnt; base_out = base;
 }
 
@@ -184,9 +199,9 @@ __device__ __forceinline__ void merge_bulk(SweepLds& L, int S, int row, int t, i
     long long n_iter = 0, n_hbm = 0, n_refill = 0;
 #endif
     // entry idx of (range seg, this row) as (2 v, f, z, v^2); from the LDS ring when it is still there, else from HBM
-    auto fetch = [&](int seg, int idx, int sbase, int sslot) -> float4 {
+    auto fetch = [&](int seg, int idx, int sbase, int sslot, bool need) -> float4 {
         float4 e = ring[idx & (kRing - 1)][seg * 64 + row];
-        const bool hb = idx < sbase;
+        const bool hb = need && idx < sbase;
         if (__builtin_amdgcn_ballot_w64(hb) != 0ull) {
 #ifdef FDCM_LAB
             ++n_hbm;
@@ -198,45 +213,64 @@ __device__ __forceinline__ void merge_bulk(SweepLds& L, int S, int row, int t, i
         }
         return e;
     };
-    // The incoming entries of every junction are fetched together before the first one is needed (one trip to memory for
-    // all of them; the sets rotate through named registers): lane t holds the entries t and t + 8 of the range as
-    // (2 v, f + v^2, local z).
+    // The first 8 incoming entries of every junction are fetched together before the first one is needed (one trip to
+    // memory for all of them; the sets rotate through named registers): lane t holds entry t of the range as
+    // (2 v, f + v^2, local z).  (Entries 8 .. 15 only come with a refill: rows scatter over memory, and the fetches of a
+    // whole chip's junctions at once cost their bytes -- the 16-entry form took 8 us here, p50.)
     struct Cand { float a2v, ahq, az, b2v, bhq, bz; };
-    auto load_cand = [&](int w, int cb) -> Cand {
+    auto load_cand = [&](int w, int cb, bool both) -> Cand {
         Cand c{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (w < S) {
             const int nw = L.t_cnt[w][row], ws = L.s_slot0[w];
-            const EnvEntry ea = entr[ws + min(cb + t, nw - 1)], eb = entr[ws + min(cb + t + 8, nw - 1)];
-            const float av = (float)ea.v, bv = (float)eb.v;
+            const EnvEntry ea = entr[ws + min(cb + t, nw - 1)];
+            const float av = (float)ea.v;
             c.a2v = av + av; c.ahq = ea.f + av * av; c.az = ea.z;
-            c.b2v = bv + bv; c.bhq = eb.f + bv * bv; c.bz = eb.z;
+            if (both) {
+                const EnvEntry eb = entr[ws + min(cb + t + 8, nw - 1)];
+                const float bv = (float)eb.v;
+                c.b2v = bv + bv; c.bhq = eb.f + bv * bv; c.bz = eb.z;
+            }
         }
         return c;
     };
-    Cand c0 = load_cand(1, 0), c1 = load_cand(2, 0), c2 = load_cand(3, 0), c3 = load_cand(4, 0), c4 = load_cand(5, 0), c5 = load_cand(6, 0), c6 = load_cand(7, 0);
+#ifdef FDCM_LAB
+    const long long lt0 = wall_clock64();
+    long long lt_loop = 0, lt_first = 0;
+#endif
+    Cand c0 = load_cand(1, 0, false), c1 = load_cand(2, 0, false), c2 = load_cand(3, 0, false), c3 = load_cand(4, 0, false), c4 = load_cand(5, 0, false), c5 = load_cand(6, 0, false), c6 = load_cand(7, 0, false);
+#ifdef FDCM_LAB
+    asm volatile("; lab: the incoming entries have arrived" :: "v"(c0.a2v), "v"(c1.a2v), "v"(c2.a2v), "v"(c3.a2v), "v"(c4.a2v), "v"(c5.a2v), "v"(c6.a2v), "v"(c6.bz));
+    const long long lt1 = wall_clock64();
+#endif
     int ms = 0, mi = L.t_cnt[0][row] - 1, ms_lo = 0, ms_base = L.t_base[0][row], ms_slot = L.s_slot0[0];  // the top of the row's stack
     L.t_lo[0][row] = 0;
 #pragma unroll 1
     for (int w = 1; w < S; ++w) {
         const int nw = L.t_cnt[w][row], wbase = L.t_base[w][row], wslot = L.s_slot0[w];
-        // window of 16 incoming entries starting at entry cb: lane t holds cb + t (A) and cb + t + 8 (B)
-        float A2v = c0.a2v, Ahq = c0.ahq, Az = c0.az, B2v = c0.b2v, Bhq = c0.bhq, Bz = c0.bz;
+        // window of incoming entries starting at entry cb: lane t holds cb + t (A) and, after a refill, cb + t + 8 (B)
+        float A2v = c0.a2v, Ahq = c0.ahq, Az = c0.az, B2v = 0.f, Bhq = 0.f, Bz = 0.f;
+        int wend = 7;  // last window index that is held
         c0 = c1; c1 = c2; c2 = c3; c3 = c4; c4 = c5; c5 = c6;
         int cur = 0, cb = 0;
         bool done = false;
         float zc = 0.f;
+        // the incoming entry and the local z of the entry behind it, in every lane of the row
+        float c2v = __shfl(A2v, sh), chq = __shfl(Ahq, sh), nz = __shfl(Az, sh + 1);
+        if (nw < 2) nz = f_inf();
+#ifdef FDCM_LAB
+        const long long lj0 = wall_clock64();
+        bool firstit = true;
+#endif
         for (;;) {
 #ifdef FDCM_LAB
             ++n_iter;
+            if (!firstit && lt_first == 0) lt_first = wall_clock64() - lj0;
+            firstit = false;
 #endif
             // ---- the incoming entry cur against the 8 entries at the top of the row's stack
-            const int ci = cur - cb;  // window index, 0..8
-            const int csrc = sh + (ci & 7);
-            const float cA2v = __shfl(A2v, csrc), cAhq = __shfl(Ahq, csrc), cB2v = __shfl(B2v, csrc), cBhq = __shfl(Bhq, csrc);
-            const float c2v = ci < 8 ? cA2v : cB2v, chq = ci < 8 ? cAhq : cBhq;
             const int idx = mi - t;
             const bool valid = idx >= ms_lo;
-            const float4 e = fetch(ms, max(idx, ms_lo), ms_base, ms_slot);
+            const float4 e = fetch(ms, max(idx, ms_lo), ms_base, ms_slot, valid && !done);
             // s = ((f[q] + q^2) - f[v] - v^2) / (2q - 2v), left to right in float (imgproc.h:111); pop while s <= z[k]
             const float s = envelope_quotient((chq - e.y) - e.w, c2v - e.x);
             const bool pop = valid && s <= e.z;
@@ -255,35 +289,46 @@ __device__ __forceinline__ void merge_bulk(SweepLds& L, int S, int row, int t, i
                     }
                 } else { mi -= npop; landed = true; }
             }
-            // the entry landed on (lane npop looked at it) and the quotient of that test
+            // the quotient of the test on the entry landed on (lane npop looked at it)
             const int lsrc = sh + min(npop, 7);
-            const float l2v = __shfl(e.x, lsrc), lf = __shfl(e.y, lsrc), lv2 = __shfl(e.w, lsrc), ls = __shfl(s, lsrc);
-            if (landed) zc = ls;
-            // ---- the entries behind it: entry cur + t + 1 pops entry cur + t if its local z <= the latter's quotient on the landing entry
-            const int wi = ci + t, wn = wi + 1;  // window indices of the entry and of its successor (<= 16)
-            const int ksrc = sh + (wi & 7), nsrc = sh + (wn & 7);
-            const float kA2v = __shfl(A2v, ksrc), kAhq = __shfl(Ahq, ksrc), kB2v = __shfl(B2v, ksrc), kBhq = __shfl(Bhq, ksrc);
-            const float nAz = __shfl(Az, nsrc), nBz = __shfl(Bz, nsrc);
-            const float k2v = wi < 8 ? kA2v : kB2v, khq = wi < 8 ? kAhq : kBhq, nz = wn < 8 ? nAz : nBz;
-            const float sk = t == 0 ? ls : envelope_quotient((khq - lf) - lv2, k2v - l2v);
-            const bool adv = landed && cur + t + 1 < nw && wn <= 15 && nz <= sk;
-            const unsigned a8 = (unsigned)(__builtin_amdgcn_ballot_w64(adv) >> sh) & 0xffu;
-            const int nadv = __builtin_ctz(~a8);
-            if (landed) {
-                if (nadv == 0) done = true;
-                else cur += nadv;
-            }
-            // the window ran out (more than 8 incoming entries gone): the next 16 from memory
-            if (__builtin_amdgcn_ballot_w64(!done && cur - cb >= 8) != 0ull) {
+            const float ls = __shfl(s, lsrc);
+            bool moves = false;  // the entry behind pops the one that just landed (the reference's test: same operands as in the local run)
+            if (landed) { zc = ls; moves = nz <= zc; done = !moves; }
+            if (__builtin_amdgcn_ballot_w64(moves) != 0ull) {
+                // ---- the entries behind it, 8 at once: entry cur + t + 1 pops entry cur + t if its local z <= the latter's quotient on the landing entry
+                const float l2v = __shfl(e.x, lsrc), lf = __shfl(e.y, lsrc), lv2 = __shfl(e.w, lsrc);
+                const int ci = cur - cb;             // window index of the incoming entry, 0..7
+                const int wi = ci + t, wn = wi + 1;  // .. of entry cur + t and of its successor (<= 15)
+                const int ksrc = sh + (wi & 7), nsrc = sh + (wn & 7);
+                const float kA2v = __shfl(A2v, ksrc), kAhq = __shfl(Ahq, ksrc), kB2v = __shfl(B2v, ksrc), kBhq = __shfl(Bhq, ksrc);
+                const float nAz = __shfl(Az, nsrc), nBz = __shfl(Bz, nsrc);
+                const float k2v = wi < 8 ? kA2v : kB2v, khq = wi < 8 ? kAhq : kBhq, nzk = wn < 8 ? nAz : nBz;
+                const float sk = t == 0 ? ls : envelope_quotient((khq - lf) - lv2, k2v - l2v);
+                const bool adv = moves && cur + t + 1 < nw && wn <= wend && nzk <= sk;
+                const unsigned a8 = (unsigned)(__builtin_amdgcn_ballot_w64(adv) >> sh) & 0xffu;
+                if (moves) cur += __builtin_ctz(~a8);  // (at least one: lane 0's test is the one that said so)
+                // the window ran out (the incoming entry's successor is not held any more): the next 16 from memory
+                if (__builtin_amdgcn_ballot_w64(moves && cur - cb >= wend) != 0ull) {
 #ifdef FDCM_LAB
-                ++n_refill;
+                    ++n_refill;
 #endif
-                if (!done && cur - cb >= 8) cb = cur;
-                const Cand c = load_cand(w, cb);
-                A2v = c.a2v; Ahq = c.ahq; Az = c.az; B2v = c.b2v; Bhq = c.bhq; Bz = c.bz;
+                    if (moves && cur - cb >= wend) cb = cur;
+                    const Cand c = load_cand(w, cb, true);
+                    A2v = c.a2v; Ahq = c.ahq; Az = c.az; B2v = c.b2v; Bhq = c.bhq; Bz = c.bz;
+                    wend = 15;
+                }
+                // the new incoming entry and its successor's z, to every lane of the row
+                const int ni = cur - cb, nn = ni + 1;  // 0..7, 1..8
+                const int s1 = sh + (ni & 7), s2 = sh + (nn & 7);
+                const float rA2v = __shfl(A2v, s1), rAhq = __shfl(Ahq, s1), rAz = __shfl(Az, s2), rBz = __shfl(Bz, s2);
+                c2v = rA2v; chq = rAhq;
+                nz = cur + 1 < nw ? (nn < 8 ? rAz : rBz) : f_inf();
             }
             if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;
         }
+#ifdef FDCM_LAB
+        lt_loop += wall_clock64() - lj0;
+#endif
         L.t_hi[ms][row] = mi;
         L.t_prev[w][row] = ms;
         L.t_lo[w][row] = cur;
@@ -293,7 +338,7 @@ __device__ __forceinline__ void merge_bulk(SweepLds& L, int S, int row, int t, i
     }
     L.t_hi[ms][row] = mi;
 #ifdef FDCM_LAB
-    if (lab && (threadIdx.x & 63) == 0) { lab[12] = n_iter; lab[13] = n_hbm; lab[14] = n_refill; }
+    if (lab && (threadIdx.x & 63) == 0) { lab[12] = n_iter; lab[13] = n_hbm; lab[14] = n_refill; lab[15] = ((lt1 - lt0) << 40) | (lt_loop << 20) | lt_first; }
 #endif
 }
 
@@ -639,6 +684,11 @@ void launch_sweep_balanced(hipStream_t st, const void* desc, float* vol, int W, 
                     fprintf(stderr, "[sweep lab] late block %ld (slice %ld chunk %ld): %.1f -> %.1f us | local %.1f merge %.1f walk %.1f fill %.1f | columns %lld deepest %lld merge steps %lld (hbm %lld, refills %lld) owners %lld\n",
                             ch, ch / HW64, ch % HW64, st0, ends[i].first, ph[0], ph[2], ph[4], ph[6], cols, depth, iters, hbm, refill, owners);
                 }
+            }
+            {
+                std::vector<double> a, b, c;
+                for (long ch = 0; ch < nchunks; ++ch) for (int w = 0; w < kSeg; ++w) { const long long v = d[((size_t)ch * kSeg + w) * 16 + 15]; if (!d[((size_t)ch * kSeg + w) * 16]) continue; a.push_back((double)(v >> 40) / 100.0); b.push_back((double)((v >> 20) & 0xfffff) / 100.0); c.push_back((double)(v & 0xfffff) / 100.0); }
+                fprintf(stderr, "[sweep lab] merge: incoming entries arrive after p50 %.1f p90 %.1f us; junction loops p50 %.1f p90 %.1f us; first step of the first junction p50 %.2f p90 %.2f us\n", pct(a, .5), pct(a, .9), pct(b, .5), pct(b, .9), pct(c, .5), pct(c, .9));
             }
             fprintf(stderr, "[sweep lab] columns per wave p50 %.0f max %.0f; deepest local stack p50 %.0f p99 %.0f max %.0f; merge iterations per block p50 %.0f p90 %.0f max %.0f, with an HBM fetch p50 %.0f p90 %.0f max %.0f\n",
                     pct(cols, .5), pct(cols, 1.0), pct(lst, .5), pct(lst, .99), pct(lst, 1.0), pct(it, .5), pct(it, .9), pct(it, 1.0), pct(hb, .5), pct(hb, .9), pct(hb, 1.0));
