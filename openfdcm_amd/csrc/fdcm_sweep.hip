@@ -318,10 +318,10 @@ __device__ __forceinline__ void merge_bulk(SweepLds& L, int S, int row, int t, i
                     wend = 15;
                 }
                 // the new incoming entry and its successor's z, to every lane of the row
-                const int ni = cur - cb, nn = ni + 1;  // 0..7, 1..8
+                const int ni = cur - cb, nn = ni + 1;  // window indices of the incoming entry and of its successor (<= wend)
                 const int s1 = sh + (ni & 7), s2 = sh + (nn & 7);
-                const float rA2v = __shfl(A2v, s1), rAhq = __shfl(Ahq, s1), rAz = __shfl(Az, s2), rBz = __shfl(Bz, s2);
-                c2v = rA2v; chq = rAhq;
+                const float rA2v = __shfl(A2v, s1), rAhq = __shfl(Ahq, s1), rB2v = __shfl(B2v, s1), rBhq = __shfl(Bhq, s1), rAz = __shfl(Az, s2), rBz = __shfl(Bz, s2);
+                c2v = ni < 8 ? rA2v : rB2v; chq = ni < 8 ? rAhq : rBhq;
                 nz = cur + 1 < nw ? (nn < 8 ? rAz : rBz) : f_inf();
             }
             if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;
