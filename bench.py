@@ -18,8 +18,10 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with these extra
                    frames measured right after the timed region, HIP events on the handle's own stream), against
                    8 TB/s; per-kernel table beside it, and the same stages as timed inside the (overlapped) timed region
   roofline_search  the search kernels: 8 B x translations scored by the reference rule x lines per template
-  parity_gate      first --cpu-sample templates: the GPU's match records against the CPU oracle's, bit for bit
-  cpu_baseline     the CPU oracle (a port; the reference cannot be built here) on the same bounded sample
+  parity_gate      the GPU's match records against the CPU oracle's, bit for bit -- at N > 1 the GATHERED list of all ranks
+                   (rank 0 runs the oracle on the whole job's template list)
+  cpu_baseline     the CPU oracle (a port; the reference cannot be built here) on the same job, on rank 0's host cores
+  scaling_bounds   what N GPUs can do to a blocking frame (the build is replicated): strong and weak
 A failed parity gate makes the run exit non-zero.
 """
 import argparse
@@ -46,7 +48,7 @@ HBM_PEAK_GBS = 8000.0
 # V/16 of column descriptors and never materialises it); propagation reads V and writes V; line integral likewise.
 STAGE_BYTES_V = {"pass2_ms": 3.0, "propagate_ms": 2.0, "integral_ms": 2.0}
 STAGE_KERNELS = {"seeds_ms": "k_seeds", "pass1_ms": "k_coldesc",
-                 "pass2_ms": "L2 / L2^2: k_sweep (+ the gated k_pass2_l2 redo); L1: k_l1_forward + k_l1_backward",
+                 "pass2_ms": "L2 / L2^2: k_sweep_balanced (k_pass2_l2 above 2896 px); L1: k_l1_word_mins + k_l1_carries + k_l1_word",
                  "propagate_ms": "k_propagate_reg", "integral_ms": "k_integral"}
 DIST_NAMES = {0: "L2", 1: "L2_SQUARED", 2: "L1"}
 # templates per GPU of the BASELINE configs (4 and 5 are sharded over 8 GPUs)
@@ -71,7 +73,6 @@ def pmc_traffic(config):
     if doc.get("so_sha256_16") != so_hash():
         return None, f"{os.path.basename(files[-1])} was measured on another build of libfdcm_hip.so"
     build = [v["hbm_bytes_per_launch"] * v.get("launches_per_frame", 1.0) for k, v in doc["kernels"].items()
-             # a blocking build: k_sweep, not the three-launch form the pipeline slots use (k_env, k_addend, k_fill)
              if any(t in k for t in ("k_seeds", "k_coldesc", "k_sweep", "k_pass2", "k_l1", "k_propagate", "k_integral"))]
     return float(sum(build)), os.path.basename(files[-1])
 
@@ -273,7 +274,7 @@ def main():
 
     # untimed extra: blocking frames (one in flight, the GPU to itself) for the roofline objects
     single = None
-    if rank == 0 and world == 1 and args.single_frames > 0:
+    if rank == 0 and args.single_frames > 0:  # (N > 1: the other ranks wait at the closing barrier meanwhile)
         fm = DeviceFeatureMap.build(scene, depth=cfg["depth"], coeff=5.0, padding=1.0, distance=cfg["distance"])
         for _ in range(5):
             fm.rebuild(scene)
@@ -314,7 +315,8 @@ def main():
                        "templates_total": total_templates, "matches_per_step": n_matches, "frames_in_flight": F,
                        "distinct_scenes": n_scenes,
                        "parallelism": f"template shards x{world}, DT3 replicated, 1 RCCL gather per frame",
-                       "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES")},
+                       "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+                       "orientation_bins": "host libm" if _capi.lib().fdcm_orientation_bins_mode() else "device atanf"},
             "frame_latency_ms": {"p50": float(np.percentile(lat, 50)), "p95": float(np.percentile(lat, 95)),
                                  "max": float(lat.max()), "note": "submit -> matches on the host, F frames in flight",
                                  # the slowest frame: its position and what its GPU spans were (a stalled host shows
@@ -356,11 +358,24 @@ def main():
                                       "avg_launch_ms": single["search_kernel_ms"],
                                       "note": "8 B x translations scored by the reference rule x lines per template; "
                                               "random 4-byte gathers move a 64-byte sector each, informational"}
+            # what N GPUs can do to one blocking frame: every GPU rebuilds the volume (b), the search (s) is what shards
+            b_ms = span
+            s_ms_ = max(single["frame_ms"] - span, single["search_kernel_ms"])
+            out["scaling_bounds"] = {
+                "note": "from this run's blocking frame: build b (replicated on every GPU) and the rest of the frame s (sharded); "
+                        "strong = (b + s) / (b + s / N) on the config's own template count, weak = N (per-GPU work fixed; one "
+                        "32-byte-record gather per frame is the only shared step)",
+                "b_ms": b_ms, "s_ms": s_ms_,
+                "strong_speedup_bound": {str(n): (b_ms + s_ms_) / (b_ms + s_ms_ / n) for n in (1, 2, 4, 8)},
+                "weak_speedup_bound": {str(n): float(n) for n in (1, 2, 4, 8)}}
             out["single_frame_ms"] = single["frame_ms"]
             out["single_frame_matches_per_s"] = n_matches / (single["frame_ms"] * 1e-3)
-        if args.cpu_sample != 0 and world == 1:  # rank 0 at N=1 only
-            sample = per_gpu if args.cpu_sample < 0 else min(args.cpu_sample, per_gpu)
-            out["cpu_baseline"], want0 = cpu_baseline(cfg, scene, all_templates[:per_gpu], sample, args.cpu_reps)
+        if args.cpu_sample != 0:
+            # Rank 0 at every N: the oracle runs the WHOLE job's template list (all shards), so at N > 1 the gate compares the
+            # GATHERED list -- every rank's records after the RCCL exchange, in the reference's positional order
+            # (defaultmatch.cpp:76-86) -- and the baseline is timed on the same job the N GPUs ran.
+            sample = total_templates if args.cpu_sample < 0 else min(args.cpu_sample, total_templates)
+            out["cpu_baseline"], want0 = cpu_baseline(cfg, scene, all_templates[:total_templates], sample, args.cpu_reps)
 
             def same_as_oracle(got_all, want):
                 got = got_all[got_all["tmpl_idx"] < sample]
@@ -379,7 +394,8 @@ def main():
                 same = len(kept) == K and all(same_as_oracle(np.asarray(res), wants[si]) for si, res in kept)
                 checked, n_rec = len(kept), sum(len(wants[si]) for si, _ in kept)
             out["parity_gate"] = "ok" if same else "FAILED"
-            out["parity_gate_detail"] = (f"match records of the first {sample} templates of "
+            out["parity_gate_detail"] = (("the gathered list of all ranks: " if world > 1 else "") +
+                                         f"match records of the first {sample} templates of "
                                          f"{'the last timed frame' if n_scenes == 1 else f'all {checked} timed frames ({n_scenes} scenes cycled)'}"
                                          f" ({n_rec} records) against the CPU oracle, bit for bit")
             gate_failed = not same

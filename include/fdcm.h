@@ -274,6 +274,12 @@ int fdcm_topk(fdcm_featuremap* fm, const fdcm_templates* templates, const fdcm_m
 /* Compare the device-portable atanf restatement with this machine's libm atanf over the float
  * bit patterns first, first+stride, ... (count values); returns the number of mismatches. */
 int64_t fdcm_selftest_atanf(uint32_t first, uint32_t stride, uint64_t count);
+/* Where the searches of this process take the orientation bins of the aligned template lines from (closestOrientation,
+ * dt3cpu.h:93-114, on atanf, math.h:295-299): 0 = the device's restatement of atanf (it agrees with this machine's libm
+ * on the sample the first search checks), 1 = this machine's libm on host threads (the sample disagreed -- another
+ * glibc -- or FDCM_FORCE_HOST_BINS=1; slower: every search recomputes align / transform / atanf of every candidate
+ * line on the host, and says so once on stderr).  Decided at the first call of this function or of a search. */
+int fdcm_orientation_bins_mode(void);
 
 #ifdef __cplusplus
 }

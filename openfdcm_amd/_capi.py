@@ -98,6 +98,7 @@ SYMBOLS = [
     ("fdcm_penalize", C.c_int, [C.c_int, C.c_float, _vp, C.c_int64, _fp, C.c_int64]),
     ("fdcm_sort_matches", C.c_int, [_vp, C.c_int64]),
     ("fdcm_selftest_atanf", C.c_int64, [C.c_uint32, C.c_uint32, C.c_uint64]),
+    ("fdcm_orientation_bins_mode", C.c_int, []),
 ]
 
 _lib = None

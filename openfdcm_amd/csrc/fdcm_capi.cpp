@@ -544,4 +544,6 @@ int64_t fdcm_selftest_atanf(uint32_t first, uint32_t stride, uint64_t count) {
     return (int64_t)total;
 }
 
+int fdcm_orientation_bins_mode(void) { return fdcm::orientation_bins_on_host() ? 1 : 0; }
+
 }  // extern "C"

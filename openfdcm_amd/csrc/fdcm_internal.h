@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -150,6 +151,8 @@ struct fdcm_featuremap {
     fdcm::DevBuf s_tail;    // device tail (penalise + sort + top k) workspace
     fdcm::DevBuf s_tail_out; // the k best of the device tail before their download
     fdcm::DevBuf s_eval;    // fdcm_featuremap_evaluate / _minmax_translation: lines, translations, work items, results
+    std::mutex seam_mutex;  // .. which the reference's optimisers call from pool threads on one feature map (batchoptimize.cpp:102-110):
+                            // the two calls share s_eval and the stream, so they take turns
     int64_t last_n_out = 0; // matches of the last host-output search, still in s_out
     fdcm::DevBuf s_counter;
     fdcm::PinnedBuf s_stage;
@@ -182,6 +185,8 @@ int64_t search_capacity(const fdcm_templates* t, int64_t n_scene, int64_t maxT, 
 void run_search(fdcm_featuremap* fm, const fdcm_templates* t, const float* scene, int64_t n_scene, int64_t maxT,
                 int64_t maxS, int optimizer, int64_t batch, int32_t base, fdcm_match* out_device, fdcm_match** out_host,
                 int64_t* n_out);
+// the searches of this process take the candidates' orientation bins from the host libm (decided once: see fdcm.h)
+bool orientation_bins_on_host();
 // implemented in fdcm_seam.hip: minmaxTranslation<Dt3Cpu> / evaluate<Dt3Cpu> batched over templates
 void run_minmax(fdcm_featuremap* fm, const float* lines, const int64_t* offsets, int64_t T, const float* align, float* out);
 void run_evaluate(fdcm_featuremap* fm, const float* lines, const int64_t* offsets, int64_t T, const float* translations,

@@ -13,6 +13,10 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "envelope_quotient is checked against the division for gfx950's v_rcp_f32 only (tools/div_check.hip): run the check for the new target before building for it"
+#endif
+
 namespace fdcm {
 
 __device__ __forceinline__ float envelope_quotient(float N, float D) {

@@ -83,6 +83,7 @@ __global__ void __launch_bounds__(256) k_evaluate(const float* __restrict__ vol,
 
 void run_minmax(fdcm_featuremap* fm, const float* lines, const int64_t* offsets, int64_t T, const float* align, float* out) {
     if (T == 0) return;
+    std::lock_guard<std::mutex> turn(fm->seam_mutex);  // concurrent callers of one feature map (a pool's tasks) take turns
     FDCM_HIP(hipSetDevice(fm->device));
     if (!fm->stream) FDCM_HIP(hipStreamCreateWithFlags(&fm->stream, hipStreamNonBlocking));
     hipStream_t st = fm->stream;
@@ -108,6 +109,7 @@ void run_evaluate(fdcm_featuremap* fm, const float* lines, const int64_t* offset
     if (T == 0 || tr_offsets[T] == 0) return;
     if (fm->vol_stage != 3) throw std::string("the feature map holds a partial build (no line integral): nothing to evaluate");
     if (fm->m == 0 || fm->W == 0 || fm->H == 0) throw std::string("evaluate on an empty feature map");
+    std::lock_guard<std::mutex> turn(fm->seam_mutex);  // concurrent callers of one feature map (a pool's tasks) take turns
     finish_build(fm);
     FDCM_HIP(hipSetDevice(fm->device));
     if (!fm->stream) FDCM_HIP(hipStreamCreateWithFlags(&fm->stream, hipStreamNonBlocking));

@@ -21,6 +21,7 @@
 // every decision -- are the reference's bit for bit; translations scored speculatively but never
 // reached by the rule are simply not read.
 #include <algorithm>
+#include <cstdio>
 #include <atomic>
 #include <chrono>
 #include <cstring>
@@ -534,6 +535,19 @@ int64_t search_capacity(const fdcm_templates* t, int64_t n_scene, int64_t maxT, 
     return total;
 }
 
+bool orientation_bins_on_host() {
+    static const bool on_host = [] {
+        const bool forced = getenv("FDCM_FORCE_HOST_BINS") != nullptr;
+        const bool differs = fdcm_selftest_atanf(0, 65537, (1ull << 32) / 65537) != 0;
+        if (forced || differs)
+            fprintf(stderr, "libfdcm_hip: orientation bins of the candidates come from this machine's libm on host threads (%s); "
+                            "searches are slower than with the device's atanf (fdcm_orientation_bins_mode() == 1)\n",
+                    differs ? "its atanf differs from the glibc 2.35 restatement the device runs" : "FDCM_FORCE_HOST_BINS is set");
+        return forced || differs;
+    }();
+    return on_host;
+}
+
 void run_search(fdcm_featuremap* fm, const fdcm_templates* t, const float* scene, int64_t n_scene, int64_t maxT,
                 int64_t maxS, int optimizer, int64_t batch, int32_t base, fdcm_match* out_device, fdcm_match** out_host,
                 int64_t* n_out) {
@@ -547,7 +561,7 @@ void run_search(fdcm_featuremap* fm, const fdcm_templates* t, const float* scene
     // few ms); on a mismatch the bins of every candidate's lines are computed on the host instead -- same transform,
     // this machine's atanf, a few host threads, overlapping the build that is still running on the device -- so that
     // parity is defined against the box's own libm, as the reference's would be.  FDCM_FORCE_HOST_BINS=1 forces it.
-    static const bool host_bins_needed = fdcm_selftest_atanf(0, 65537, (1ull << 32) / 65537) != 0 || getenv("FDCM_FORCE_HOST_BINS") != nullptr;
+    const bool host_bins_needed = orientation_bins_on_host();
     FDCM_HIP(hipSetDevice(fm->device));
     if (!fm->stream) FDCM_HIP(hipStreamCreateWithFlags(&fm->stream, hipStreamNonBlocking));
     if (!fm->timing.created) {

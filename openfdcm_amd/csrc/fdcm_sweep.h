@@ -17,6 +17,7 @@ struct SweepBuf {
     int* cost;                            // per chunk: 100 MHz ticks from the block's start to the end of its owner walk
     int eslots, lslots;
     const unsigned long long* colmask;    // [slice][(W + 63) / 64]: the slice's seeded columns (k_coldesc_tile)
+    int min_cols;                         // seeded columns a range holds at least (set by the launcher)
 #ifdef FDCM_LAB
     long long* lab;                       // lab builds (make LAB=1): 16 clock stamps / counters per (chunk, wave), or null
 #endif
@@ -27,5 +28,11 @@ inline bool sweep_balanced_applies(long W, long H) { return W * W + H * H <= (1L
 
 // queues the sweep of nchunks (slice, 64-row chunk) pairs on st; vol receives the transforms in the interleaved layout
 void launch_sweep_balanced(hipStream_t st, const void* desc, float* vol, int W, int H, int HW64, long nchunks, const SweepBuf& B);
+// launch order of the next sweep: chunks by decreasing cost (one workgroup; order = a permutation of 0 .. n - 1 whatever the costs are)
+void launch_sweep_order(hipStream_t st, const int* cost, int n, int* order);
+
+// fdcm_sweep_literal.hip: the reference's pass followed literally, one wave per chunk -- any feature size
+size_t sweep_literal_scratch_bytes(int W, long nchunks);
+void launch_sweep_literal(hipStream_t st, const void* desc, float* vol, int W, int H, int HW64, long nchunks, void* scratch);
 
 }  // namespace fdcm

@@ -43,7 +43,7 @@ static constexpr int kSeg = kSweepSegments;  // waves per block = column ranges 
 static constexpr int kNT = 64 * kSeg;
 static constexpr int kRing = 8;      // stack entries per (row, range) below the top kept in LDS
 static constexpr int kRE = 16;       // owner entries per row and round of the fill
-static constexpr int kMinCols = 16;  // a range holds at least this many seeded columns (fewer ranges on small slices)
+static constexpr int kMinCols = 16;  // a range holds at least this many seeded columns (fewer ranges on small slices); FDCM_SWEEP_MINCOLS
 
 struct SweepLds {
     unsigned long long smask[64];    // the slice's seeded columns, 64 per word (W <= 4096)
@@ -619,8 +619,35 @@ __global__ void __launch_bounds__(kNT) k_sweep_balanced(const ColDesc* __restric
 #undef LAB_STAMP
 }
 
-void launch_sweep_balanced(hipStream_t st, const void* desc, float* vol, int W, int H, int HW64, long nchunks, const SweepBuf& B) {
+// Launch order of the next build's chunks: by decreasing cost of this one (scenes of a stream change little from
+// frame to frame).  Blocks are dispatched in index order; when there are more blocks than the GPU holds, the
+// longest ones must not start last.  One workgroup: a counting sort over 256 cost classes.
+__global__ void __launch_bounds__(1024) k_order(const int* __restrict__ cost, int n, int* __restrict__ order) {
+    __shared__ int hist[256], cursor[256], smax;
+    const int tid = threadIdx.x;
+    if (tid < 256) hist[tid] = 0;
+    if (tid == 0) smax = 1;
+    __syncthreads();
+    int mx = 1;
+    for (int i = tid; i < n; i += 1024) mx = max(mx, cost[i]);
+    atomicMax(&smax, mx);
+    __syncthreads();
+    const float scale = 255.f / (float)smax;
+    for (int i = tid; i < n; i += 1024) atomicAdd(&hist[255 - min(255, max(0, (int)((float)cost[i] * scale)))], 1);
+    __syncthreads();
+    if (tid == 0) { int run = 0; for (int b = 0; b < 256; ++b) { cursor[b] = run; run += hist[b]; } }
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) order[atomicAdd(&cursor[255 - min(255, max(0, (int)((float)cost[i] * scale)))], 1)] = i;
+}
+
+void launch_sweep_order(hipStream_t st, const int* cost, int n, int* order) { hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, st, cost, n, order); }
+
+void launch_sweep_balanced(hipStream_t st, const void* desc, float* vol, int W, int H, int HW64, long nchunks, const SweepBuf& B_) {
     const int part_w = (((W + kSeg - 1) / kSeg) + 3) & ~3;  // fill parts start on a group of 4 columns
+    // FDCM_SWEEP_MINCOLS=1..64 is the tests' switch: small images then take all 8 ranges too (their slices have few columns)
+    static const int env_min_cols = [] { const char* e = getenv("FDCM_SWEEP_MINCOLS"); const int v = e ? atoi(e) : 0; return (v >= 1 && v <= 64) ? v : kMinCols; }();
+    SweepBuf B = B_;
+    B.min_cols = env_min_cols;
 #ifdef FDCM_LAB
     if (getenv("FDCM_SWEEP_LAB")) {  // per-wave phase times (100 MHz clock) and counters of this launch, on stderr
         static DevBuf labbuf;

@@ -526,20 +526,21 @@ def test_search_many_templates_generic_work_list(amd):
 
 
 @pytest.mark.parametrize("env,cases,seed", [({}, 80, 11),
-                                            ({"FDCM_K2_SEGMENTS": "8", "FDCM_K2_FORCE_REDO": "5"}, 40, 12),
-                                            ({"FDCM_K2_SEGMENTS": "3"}, 40, 13),
-                                            ({"FDCM_K2_LEGACY": "1"}, 40, 14),
+                                            ({"FDCM_SWEEP_MINCOLS": "2"}, 60, 12),
+                                            ({"FDCM_SWEEP_MINCOLS": "1", "FDCM_SWEEP_ORDER": "1"}, 40, 13),
+                                            ({"FDCM_L2_SWEEP": "literal"}, 40, 14),
                                             ({"FDCM_FORCE_HOST_BINS": "1"}, 40, 15),
                                             ({"FDCM_INT_XC": "256"}, 30, 16),
                                             ({"FDCM_INT_XC": "128"}, 30, 17),
                                             ({"FDCM_SEARCH_FLAT": "1"}, 30, 18)],
-                         ids=["default", "8-segments+forced-redo", "3-segments", "one-wave-per-chunk", "host-libm-bins",
+                         ids=["default", "8-ranges-on-small-slices", "1-column-ranges+launch-order", "literal-one-wave-per-chunk", "host-libm-bins",
                               "integral-252-chain-blocks", "integral-124-chain-blocks", "search-with-64-bit-addresses"])
 def test_randomised_cases(amd, env, cases, seed):
     """Random (scene, depth, distance, padding, coefficient, optimiser, template set) cases: volume and match list
     bit for bit (tools/fuzz_parity.py).  The variants force the paths of the L2 sweep that the default sizes do not
-    take: eight segments per row with every fifth chunk sent through the redo path (a failed junction check), three
-    segments, and the one-wave-per-chunk kernel alone; the orientation bins of the aligned template lines from the host
+    take: all eight column ranges per row on slices with few columns (ranges of two columns and of one: junctions that
+    pop whole ranges, rows whose stack is one entry), the launch order from a cost table, and the literal
+    one-wave-per-chunk kernel that sizes above the exact-integer bound take; the orientation bins of the aligned template lines from the host
     libm (the path a host whose atanf differs from the device restatement takes); the wide-block forms of the steep
     line integral that only large volumes select; the search with 64-bit flat addresses (what volumes of 4 GB and more take)."""
     import os
@@ -551,7 +552,7 @@ def test_randomised_cases(amd, env, cases, seed):
     assert out.returncode == 0 and f"{cases} random cases identical" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
 
-@pytest.mark.parametrize("env", [{}, {"FDCM_K2_LPT": "1"}], ids=["default", "launch-order-from-history"])
+@pytest.mark.parametrize("env", [{}, {"FDCM_SWEEP_ORDER": "1"}], ids=["default", "launch-order-from-history"])
 def test_rebuilds_of_one_handle(amd, env):
     """A handle rebuilt over scenes of changing content and size (tools/rebuild_parity.py): every volume bit for bit.
     The second variant forces the L2 sweep's launch order by the previous build's chunk times at these small sizes."""

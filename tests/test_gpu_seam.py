@@ -111,6 +111,47 @@ def test_evaluate_random_batches_bit_exact(built_pair):
     assert len(dev.evaluate([], [])) == 0
 
 
+def test_evaluate_and_minmax_from_concurrent_threads(built_pair):
+    """The reference's optimisers call minmaxTranslation / evaluate on ONE feature map from the tasks of a thread pool
+    (batchoptimize.cpp:102-110, `submit_task(func(tmpl_idx))`).  Eight host threads hammer one handle with different
+    templates and translation sets (different sizes, so the shared scratch is re-laid-out between calls); every score
+    and every interval must be the oracle's bits."""
+    import threading
+    scene, dev, orc = built_pair
+    S = dev.width / 1.2
+    size = (dev.width, dev.height)
+    errors, done = [], [0] * 8
+
+    def worker(k):
+        try:
+            rng = np.random.default_rng(100 + k)
+            for it in range(6):
+                tmpls = _random_templates(rng, S, 5 + 7 * ((k + it) % 4), max_lines=10 + 6 * k)
+                trans = [rng.uniform(-0.1 * S, 0.1 * S, size=(int(rng.integers(1, 40 + 30 * (it % 3))), 2)).astype(np.float32) for _ in tmpls]
+                got = dev.evaluate(tmpls, trans)
+                for i, (t, tr) in enumerate(zip(tmpls, trans)):
+                    want = O.evaluate(orc, t, tr)
+                    if not _same_bits(got[i], want):
+                        errors.append(("evaluate", k, it, i))
+                full = [t for t in tmpls if t.shape[1] > 0]
+                avs = [O.rasterize_vector(np.cos(a), np.sin(a)) for a in rng.uniform(0, 2 * np.pi, size=len(full))]
+                mm = dev.minmax_translation_batch(full, avs)
+                for i, (t, a) in enumerate(zip(full, avs)):
+                    if not _same_bits(mm[i], O.minmax_translation(t, a, size, dev.scene_translation)):
+                        errors.append(("minmax", k, it, i))
+                done[k] += 1
+        except Exception as e:  # noqa: BLE001 -- reported below, on the main thread
+            errors.append(("exception", k, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(8)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors[:5]
+    assert done == [6] * 8
+
+
 def test_evaluate_outside_the_image_scores_nan(built_pair):
     scene, dev, orc = built_pair
     t = L((10, 10, 40, 30), (20, 15, 60, 18))

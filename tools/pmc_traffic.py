@@ -36,7 +36,7 @@ def main():
     fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
     out = {}
     # access pattern of each kernel's HBM reads (see the module docstring)
-    patterns = {"k_search": "gather", "k_evaluate": "gather", "k_sweep": "mixed", "k_env": "mixed", "k_addend": "mixed",
+    patterns = {"k_search": "gather", "k_evaluate": "gather", "k_sweep": "mixed",
                 "k_pass2_l2": "mixed", "k_topk": "mixed"}
     for k in sorted(set(fetch) | set(write)):
         if not k.startswith("fdcm::"):

@@ -2,7 +2,7 @@
 """One feature-map handle rebuilt over a sequence of scenes (same size, changing content; then a different size and
 back): every volume bit for bit against the oracle.  Exercises what only a reused handle has: buffers that are not
 reallocated, the cleared-in-place seed bitmap, and the launch order taken from the previous build's chunk times
-(FDCM_K2_LPT=1 forces it at small sizes).  usage: rebuild_parity.py [n_rebuilds] [seed]"""
+(FDCM_SWEEP_ORDER=1 forces it at small sizes).  usage: rebuild_parity.py [n_rebuilds] [seed]"""
 import os
 import sys
 import numpy as np
