@@ -10,7 +10,80 @@
 
 #include "fdcm.h"
 
-int main(void) {
+/* Config 1 of BASELINE.json from the reference's own asset files: `fdcm_example <dir>` reads <dir>/scene_0.scene and
+ * <dir>/template_0.tmpl, template_1.tmpl, .. (as many as there are) with fdcm_lines_read, builds the feature map
+ * (depth 30, coeff 5, padding 1.0, L2), searches with DefaultSearch(4, 4) + BatchOptimize(10) and prints the match
+ * count and the three best matches after ExponentialPenalty(1.5) + sort -- the notebook's sequence. */
+static int run_assets(const char* dir) {
+    char path[1024];
+    float* scene = NULL;
+    int64_t n_scene = 0;
+    snprintf(path, sizeof(path), "%s/scene_0.scene", dir);
+    if (fdcm_lines_read(path, &scene, &n_scene) != FDCM_OK) { printf("%s\n", fdcm_last_error()); return 2; }
+    float* all = NULL;
+    int64_t cap = 0, n_all = 0, T = 0;
+    int64_t* offsets = (int64_t*)malloc(sizeof(int64_t));
+    offsets[0] = 0;
+    for (;;) {
+        float* t = NULL;
+        int64_t n = 0;
+        snprintf(path, sizeof(path), "%s/template_%lld.tmpl", dir, (long long)T);
+        if (fdcm_lines_read(path, &t, &n) != FDCM_OK) break;  /* the first missing number ends the list */
+        if (n_all + n > cap) { cap = 2 * (n_all + n); all = (float*)realloc(all, (size_t)cap * 4 * sizeof(float)); }
+        for (int64_t i = 0; i < 4 * n; ++i) all[4 * n_all + i] = t[i];
+        fdcm_lines_free(t);
+        n_all += n;
+        ++T;
+        offsets = (int64_t*)realloc(offsets, (size_t)(T + 1) * sizeof(int64_t));
+        offsets[T] = n_all;
+    }
+    printf("assets: %lld scene lines, %lld templates, %lld template lines\n", (long long)n_scene, (long long)T, (long long)n_all);
+    /* write + read back: the writer makes files the reader (and the reference) takes */
+    snprintf(path, sizeof(path), "%s", "/tmp/fdcm_example_roundtrip.lines");
+    float* back = NULL;
+    int64_t n_back = 0;
+    if (fdcm_lines_write(path, scene, n_scene) != FDCM_OK || fdcm_lines_read(path, &back, &n_back) != FDCM_OK || n_back != n_scene) {
+        printf("round trip failed: %s\n", fdcm_last_error());
+        return 2;
+    }
+    for (int64_t i = 0; i < 4 * n_scene; ++i) if (back[i] != scene[i]) { printf("round trip differs\n"); return 2; }
+    fdcm_lines_free(back);
+    remove(path);
+    fdcm_featuremap* fm = NULL;
+    fdcm_templates* ts = NULL;
+    int ndev = 0;
+    if (fdcm_device_count(&ndev) != FDCM_OK || ndev == 0 || fdcm_featuremap_build(scene, n_scene, 30, 5.f, 1.0f, FDCM_L2, &fm) != FDCM_OK) {
+        printf("no HIP device: %s\n", fdcm_last_error());
+        return 0;
+    }
+    fdcm_match* out = NULL;
+    int64_t n = 0;
+    if (fdcm_templates_create(all, offsets, T, &ts) != FDCM_OK ||
+        fdcm_search(fm, ts, scene, n_scene, 4, 4, FDCM_BATCH_OPTIMIZE, 10, 0, &out, &n) != FDCM_OK) {
+        printf("%s\n", fdcm_last_error());
+        return 2;
+    }
+    fdcm_featuremap_info info;
+    fdcm_featuremap_get_info(fm, &info);
+    printf("config 1: feature size %lld x %lld x %lld, %lld raw matches\n", (long long)info.width, (long long)info.height,
+           (long long)info.depth, (long long)n);
+    fdcm_match* best = NULL;
+    int64_t nb = 0;
+    if (fdcm_topk(fm, ts, NULL, 0, 0, FDCM_EXPONENTIAL_PENALTY, 1.5f, 3, &best, &nb) != FDCM_OK) { printf("%s\n", fdcm_last_error()); return 2; }
+    for (int64_t i = 0; i < nb; ++i)
+        printf("  best %lld: template %d score %.9g\n", (long long)i, best[i].tmpl_idx, best[i].score);
+    fdcm_matches_free(best);
+    fdcm_matches_free(out);
+    fdcm_templates_free(ts);
+    fdcm_featuremap_free(fm);
+    fdcm_lines_free(scene);
+    free(all);
+    free(offsets);
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    if (argc > 1) return run_assets(argv[1]);
     /* a 4-line scene and one 3-line template, x1 y1 x2 y2 per line (the reference's LineArray columns) */
     const float scene[] = {0, 0, 40, 0, 40, 0, 40, 30, 40, 30, 0, 30, 0, 30, 0, 0};
     const float tmpl[] = {2, 2, 22, 2, 22, 2, 22, 17, 22, 17, 2, 17};

@@ -270,6 +270,15 @@ int fdcm_sort_matches(fdcm_match* matches, int64_t n);
 int fdcm_topk(fdcm_featuremap* fm, const fdcm_templates* templates, const fdcm_match* matches_device, int64_t n,
               int32_t tmpl_index_base, int penalty, float tau, int64_t k, fdcm_match** out, int64_t* n_out);
 
+/* ---- the reference's line files (.lines / .scene / .tmpl): read / write of core/serialization.h:99-132 (Python: openfdcm.read
+ *      / openfdcm.write, python/src/core.cpp:41-42).  Host only.  fdcm_lines_read hands out n lines as 4 floats each
+ *      (x1 y1 x2 y2 = the 4 x N column-major LineArray), to be released with fdcm_lines_free; a missing file, a file that is
+ *      not a line file and an unknown line data format are FDCM_EINVAL with the reference's message in fdcm_last_error().
+ *      fdcm_lines_write replaces an existing file, as the reference does. ---- */
+int fdcm_lines_read(const char* path, float** lines, int64_t* n_lines);
+int fdcm_lines_write(const char* path, const float* lines, int64_t n_lines);
+void fdcm_lines_free(float* lines);
+
 /* ---- host-side self checks (no GPU needed) ---- */
 /* Compare the device-portable atanf restatement with this machine's libm atanf over the float
  * bit patterns first, first+stride, ... (count values); returns the number of mismatches. */

@@ -523,6 +523,22 @@ int fdcm_sort_matches(fdcm_match* matches, int64_t n) {
     });
 }
 
+// ------------------------------------------------------------------------------------------ line files (fdcm_lineio.cpp)
+int fdcm_lines_read(const char* path, float** lines, int64_t* n_lines) {
+    return guarded([&] {
+        require(path && lines && n_lines, "null argument");
+        *lines = nullptr; *n_lines = 0;
+        lines_read(path, lines, n_lines);
+    });
+}
+int fdcm_lines_write(const char* path, const float* lines, int64_t n_lines) {
+    return guarded([&] {
+        require(path && n_lines >= 0 && (n_lines == 0 || lines), "bad arguments");
+        lines_write(path, lines, n_lines);
+    });
+}
+void fdcm_lines_free(float* lines) { std::free(lines); }
+
 // ------------------------------------------------------------------------------------------ self checks
 int64_t fdcm_selftest_atanf(uint32_t first, uint32_t stride, uint64_t count) {
     if (stride == 0) stride = 1;

@@ -206,6 +206,9 @@ inline unsigned ordered_key_host(float f) {
     __builtin_memcpy(&u, &f, 4);
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
+// the reference's line files (fdcm_lineio.cpp); lines_read hands out malloc'ed memory
+void lines_read(const char* path, float** out, int64_t* n_out);
+void lines_write(const char* path, const float* lines, int64_t n);
 // compute units of a device (cached; fdcm_capi.cpp)
 int device_cus(int device);
 // pooled pinned host buffers for match arrays returned to the caller (fdcm_host.cpp)

@@ -85,6 +85,48 @@ def test_lineio_roundtrip_and_assets(tmp_path):
         lineio.read(str(tmp_path / "missing.lines"))
 
 
+def test_lines_read_write_through_the_c_abi(capi, tmp_path):
+    """fdcm_lines_read / _write (serialization.h:99-132) against the reference's shipped files and the Python reader:
+    the same lines from the same bytes, files written through the ABI read by the Python reader and the other way
+    round, and the reference's error messages."""
+    import ctypes as C
+    from openfdcm_amd import lineio
+    lib = capi.lib()
+
+    def c_read(path):
+        p, n = C.POINTER(C.c_float)(), C.c_int64()
+        rc = lib.fdcm_lines_read(path.encode(), C.byref(p), C.byref(n))
+        if rc != 0:
+            return rc, lib.fdcm_last_error().decode()
+        a = np.ctypeslib.as_array(p, shape=(n.value, 4)).copy() if n.value else np.zeros((0, 4), np.float32)
+        lib.fdcm_lines_free(p)
+        return 0, np.ascontiguousarray(a.T)
+
+    gold = os.path.join(ROOT, "tests", "golden", "obj_04")
+    for name in ("scene_0.scene", "template_0.tmpl", "template_57.tmpl", "template_121.tmpl"):
+        rc, got = c_read(os.path.join(gold, name))
+        want = lineio.read(os.path.join(gold, name))
+        assert rc == 0 and got.shape == want.shape and got.tobytes() == want.tobytes(), name
+    rng = np.random.default_rng(3)
+    for n in (0, 1, 7, 1000):
+        lines = rng.uniform(-500, 500, size=(4, n)).astype(np.float32)
+        p1, p2 = str(tmp_path / f"c_{n}.lines"), str(tmp_path / f"py_{n}.lines")
+        rec = np.ascontiguousarray(lines.T)
+        assert lib.fdcm_lines_write(p1.encode(), capi.fptr(rec), n) == 0, lib.fdcm_last_error()
+        assert lineio.read(p1).tobytes() == lines.tobytes()           # ABI writer -> Python reader
+        lineio.write(p2, lines)
+        rc, back = c_read(p2)                                          # Python writer -> ABI reader
+        assert rc == 0 and back.tobytes() == lines.tobytes()
+        assert lib.fdcm_lines_write(p1.encode(), capi.fptr(rec), n) == 0  # an existing file is replaced
+    rc, msg = c_read(str(tmp_path / "missing.lines"))
+    assert rc == -1 and "does not exist" in msg
+    junk = tmp_path / "junk.lines"
+    junk.write_bytes(b"not a line file at all, but long enough to hold a header of 39 bytes")
+    rc, msg = c_read(str(junk))
+    assert rc == -1 and "not an OPENFDCM line file" in msg
+    assert lib.fdcm_lines_read(None, None, None) == -1
+
+
 def _build_c_example(tmp_path):
     import subprocess
     exe = str(tmp_path / "fdcm_example")
@@ -113,3 +155,28 @@ def test_c_example_on_device(capi, tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "raw matches" in out.stdout and "#0 score" in out.stdout and "seam: multipliers of (1, 0) in [" in out.stdout, out.stdout
+
+
+@pytest.mark.gpu
+def test_c_example_runs_config_1_from_the_shipped_assets(capi, tmp_path):
+    """`fdcm_example tests/golden/obj_04`: the reference's scene and its 122 templates read with fdcm_lines_read, config 1 of
+    BASELINE.json from plain C; the match count and the three best matches are the Python path's (which the parity suite
+    holds to the oracle)."""
+    import glob
+    import subprocess
+    from openfdcm_amd import lineio, _capi
+    from openfdcm_amd.engine import DeviceFeatureMap, DeviceTemplates, search_raw, topk
+    gold = os.path.join(ROOT, "tests", "golden", "obj_04")
+    exe = _build_c_example(tmp_path)
+    out = subprocess.run([exe, gold], capture_output=True, text=True, timeout=180)
+    assert out.returncode == 0, out.stdout + out.stderr
+    scene = lineio.read(os.path.join(gold, "scene_0.scene"))
+    tmpls = [lineio.read(os.path.join(gold, f"template_{i}.tmpl")) for i in range(len(glob.glob(os.path.join(gold, "*.tmpl"))))]
+    fm = DeviceFeatureMap.build(scene, depth=30, coeff=5.0, padding=1.0, distance=0)
+    tset = DeviceTemplates(tmpls)
+    raw = search_raw(fm, tset, scene, 4, 4, _capi.BATCH_OPTIMIZE, 10)
+    best = topk(fm, tset, 3, _capi.EXPONENTIAL_PENALTY, 1.5)
+    assert f"assets: {scene.shape[1]} scene lines, {len(tmpls)} templates" in out.stdout, out.stdout
+    assert f"x 30, {len(raw)} raw matches" in out.stdout, out.stdout
+    for i in range(3):
+        assert f"best {i}: template {int(best[i]['tmpl_idx'])} score {float(best[i]['score']):.9g}" in out.stdout, out.stdout
