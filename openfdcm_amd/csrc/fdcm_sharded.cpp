@@ -275,6 +275,22 @@ int64_t submit_frame(fdcm_sharded* s, Job&& job) {
     if (s->n_slots == 0) start_workers(s, 1);
     const size_t si = (size_t)(s->next_ticket % s->n_slots);
     if (s->slot_ticket[si] >= 0) throw std::string("every frame slot holds a frame that has not been waited for");
+    // Device memory of the slot is sized HERE, on the caller's thread, before its workers get the frame: an allocation is a
+    // device-wide synchronisation, and the caller's thread is also the one that runs the exchange of earlier frames (in
+    // wait) -- so an allocation can never race a grouped send/recv in flight.  The record buffers take the frame's search
+    // capacity; a slot without a feature map yet (its first frame) builds it once here, so that the worker's rebuild
+    // finds every buffer of the build in place (a later frame with a larger feature size still grows them in the worker).
+    for (auto& sh : s->shards) {
+        FrameSlot& fs = *sh.slots[si];
+        int64_t cap = 0;
+        if (fdcm_search_capacity(sh.tset, job.n_scene, job.maxT, job.maxS, &cap) != FDCM_OK) throw std::string(fdcm_last_error());
+        FDCM_HIP(hipSetDevice(sh.device));
+        (void)fdcm_set_device(sh.device);
+        fs.block.reserve(std::max<size_t>(32, (size_t)cap * sizeof(fdcm_match)));
+        if (job.topk) fs.best.reserve(std::max<size_t>(32, (size_t)std::min<int64_t>(std::max<int64_t>(job.k, 0), cap) * sizeof(fdcm_match)));
+        if (!fs.fm && fdcm_featuremap_build(job.scene.data(), job.n_scene, s->depth, s->coeff, s->padding, s->distance, &fs.fm) != FDCM_OK)
+            throw std::string(fdcm_last_error());
+    }
     for (auto& sh : s->shards) {
         FrameSlot& fs = *sh.slots[si];
         std::unique_lock<std::mutex> lk(fs.mu);

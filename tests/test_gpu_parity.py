@@ -799,6 +799,32 @@ def test_bench_force_dist_runs_the_rccl_gather_and_passes_its_parity_gate(amd):
     assert doc["roofline"]["frac"] > 0 and doc["roofline_search"]["achieved"] > 0 and doc["cpu_baseline"]["cores"] >= 1
 
 
+def test_bench_two_gpus_gates_the_gathered_list(amd):
+    """bench.py --gpus 2 (what the driver's scaling run launches): two ranks over RCCL, the gathered list of both shards
+    against the oracle on rank 0 (parity_gate) and the CPU baseline on the N > 1 line.  Runs by itself wherever two GPUs
+    are visible; the one-GPU test box skips it (the multi-GPU curve stays UNMEASURED until such a node runs this)."""
+    import ctypes as C
+    import json
+    import os
+    import subprocess
+    import sys
+    from openfdcm_amd import _capi
+    n = C.c_int()
+    _capi.check(_capi.lib().fdcm_device_count(C.byref(n)))
+    if n.value < 2:
+        pytest.skip("needs at least two GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    for scaling in ("weak", "strong"):
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "2", "--scaling", scaling,
+                              "--templates", "120", "--cpu-reps", "1", "--single-frames", "3"], capture_output=True, text=True, timeout=900, env=env)
+        assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+        doc = json.loads([l for l in out.stdout.strip().splitlines() if l.startswith("{")][-1])
+        assert doc["parity_gate"] == "ok" and doc["n_gpus"] == 2 and doc["scaling"] == scaling
+        assert "the gathered list of all ranks" in doc["parity_gate_detail"] and doc["cpu_baseline"]["cores"] >= 1
+        assert doc["config"]["templates_total"] == (240 if scaling == "weak" else 120)
+
+
 def test_envelope_quotient_is_the_division_for_every_operand_pair(amd, tmp_path):
     """The L2 sweep's envelope test divides with 4 instructions instead of the compiler's 11 (csrc/fdcm_quotient.h);
     tools/div_check.hip compares the two bit for bit on every operand pair the sweep can produce (2.75e12 pairs on this
