@@ -18,7 +18,7 @@ __device__ __forceinline__ float wave_max_f(float v) {
 // (x1,y1,x2,y2,slice), off = sceneTranslation + translation.  The two reads are split from the subtraction so that a
 // caller can have the reads of many lines in flight.
 // Two addressing forms.  VolRef::buf32 (volumes below 4 GB, i.e. every BASELINE config except 5): one buffer descriptor
-// for the whole volume, the line's slice as a 32-bit byte offset (bin * bytes per slice, written into L[5 i + 4] by
+// for the whole volume, the line's slice as a 32-bit element offset (bin * floats per slice, written into L[5 i + 4] by
 // the caller) and 24-bit multiplies -- 18 vector instructions per line where 64-bit flat addresses with a 64-bit
 // bin * slice product and full 32-bit multiplies (quarter rate) took the time of 43; k_search alone 0.145 -> measured in
 // DESIGN.md.  Otherwise: L[5 i + 4] holds the bin and addresses are 64-bit.
@@ -36,7 +36,7 @@ __device__ __forceinline__ VolRef make_volref(const float* vol, size_t SL, int m
 }
 // what the caller stores in L[5 i + 4] for a line of orientation bin `bin`
 __device__ __forceinline__ float line_slice_word(const VolRef& V, int bin) {
-    return __int_as_float(V.buf32 ? (int)((unsigned)bin * (unsigned)V.SL * 4u) : bin);  // buf32: the slice's byte offset (the volume is below 4 GB)
+    return __int_as_float(V.buf32 ? (int)((unsigned)bin * (unsigned)V.SL) : bin);
 }
 struct LineReads {
     float a, b;
@@ -49,15 +49,12 @@ __device__ __forceinline__ LineReads line_reads(const VolRef& V, const float* L,
     LineReads r;
     // the integrated volume is interleaved (ivol_index): element ((x / 4) * H + y) * 4 + x % 4 of the slice
     if (BUF32) {
-        // byte offset of element ((x / 4) * H + y) * 4 + x % 4 of the line's slice = 4 H x + 16 y - 4 (H - 1) (x % 4) + slice:
-        // two 24-bit multiply-adds per end point (4 H < 2^16, x < 2^14: exact and full rate) where the shifts, the multiply
-        // and the masks of the literal form took eight instructions; l[4] holds the slice's byte offset
-        const unsigned sb = (unsigned)__float_as_int(l[4]);  // the two halves of a wave work on different lines
-        const unsigned H4 = H << 2, Hm = (H - 1u) << 2;
-        const unsigned o1 = __umul24((unsigned)x1, H4) + ((unsigned)y1 << 4) - __umul24((unsigned)x1 & 3u, Hm) + sb;
-        const unsigned o2 = __umul24((unsigned)x2, H4) + ((unsigned)y2 << 4) - __umul24((unsigned)x2 & 3u, Hm) + sb;
-        r.a = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(V.rs, o1, 0, 0));
-        r.b = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(V.rs, o2, 0, 0));
+        const unsigned se = (unsigned)__float_as_int(l[4]);  // the two halves of a wave work on different lines
+        // x / 4 < 2^12 and H <= 2^14: the 24-bit multiply is exact (and full rate)
+        const unsigned i1 = (((__umul24((unsigned)x1 >> 2, H) + (unsigned)y1) << 2) | ((unsigned)x1 & 3u)) + se;
+        const unsigned i2 = (((__umul24((unsigned)x2 >> 2, H) + (unsigned)y2) << 2) | ((unsigned)x2 & 3u)) + se;
+        r.a = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(V.rs, i1 << 2, 0, 0));
+        r.b = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(V.rs, i2 << 2, 0, 0));
     } else {
         const float* slice = V.vol + (size_t)__float_as_int(l[4]) * V.SL;
         r.a = slice[((unsigned)(x1 >> 2) * H + (unsigned)y1) * 4u + (unsigned)(x1 & 3)];
