@@ -27,7 +27,7 @@ stats bench_config2p_frames1 python3 $R/bench.py --cpu-sample 0 --frames 1 --sin
 pmc config2p python3 $R/bench.py --frames 1 --steps 5 --warmup 2 --cpu-sample 0 --single-frames 0
 # bench.py reports `roofline.traffic` from profiles/*pmc_traffic*config2p*.json when that file was measured on the running
 # library: put the fresh one there (this copy of the repository is scratch) before the judged bench lines are taken
-cp $OUT/pmc_traffic_config2p.json $R/profiles/${2:-r03}_pmc_traffic_config2p.json
+cp $OUT/pmc_traffic_config2p.json $R/profiles/${2:-r04}_pmc_traffic_config2p.json
 python3 $R/bench.py > $OUT/bench.json 2> $OUT/bench.err
 python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_cmd.json 2>> $OUT/bench.err
 for cfg in 3 5; do
