@@ -42,7 +42,7 @@ namespace fdcm {
 static constexpr int kSeg = kSweepSegments;  // waves per block = column ranges per row = fill parts
 static constexpr int kNT = 64 * kSeg;
 static constexpr int kRing = 8;      // stack entries per (row, range) below the top kept in LDS
-static constexpr int kRE = 16;       // owner entries per row and round of the fill
+static constexpr int kRE = 10;       // owner entries per row and round of the fill (three words each in LDS)
 static constexpr int kMinCols = 16;  // a range holds at least this many seeded columns (fewer ranges on small slices); FDCM_SWEEP_MINCOLS
 
 struct SweepLds {
@@ -67,33 +67,39 @@ __device__ __forceinline__ int select_column(const unsigned long long* smask, in
 }
 
 // ---- the literal construction over the seeded columns [q0, ql] of the slice, bottom = q0 (imgproc.h:100-121)
-// ring entries: (float(2 v), f[v], z, float(v)^2)
+// Stack entries in registers and in the ring are (float(2 v), P = f[v] + v^2, z): the numerator of imgproc.h:111,
+// ((f[q] + q^2) - f[v]) - v^2, is the exact integer P_q - P_v whatever the order (every term is an integer below 2^24), so
+// the test takes one subtraction, and f[v] = P - v^2 comes back exactly where an entry leaves for memory.
+__device__ __forceinline__ EnvEntry to_mem(const float4& e) {
+    const float vf = 0.5f * e.x;
+    return EnvEntry{(int)vf, e.y - vf * vf, e.z};
+}
+__device__ __forceinline__ float4 from_mem(const EnvEntry& e) {
+    const float vf = (float)e.v;
+    return make_float4(vf + vf, e.f + vf * vf, e.z, 0.f);
+}
 __device__ __forceinline__ void local_run(const uint4* __restrict__ dp, int W, const unsigned long long* smask, int q0, int ql, int lane,
                                           int y, int tid, float4 (*ring)[kNT], EnvEntry* __restrict__ ent, int& cnt_out, int& base_out) {
     const float inf = f_inf();
     const uint4 db = dp[q0];
     // top entry t and the entry below it u (a register copy of ring entry cnt - 1, so that a single pop needs no LDS round trip)
-    float tvf = (float)q0;
-    float tf = column_value_sq_seeded(((unsigned long long)db.y << 32) | db.x, (int)db.z, (int)db.w, lane, y);
-    float tz = -inf;
-    float tv2 = tvf * tvf, tvx2 = tvf + tvf;
+    float tvx2, tP, tz = -inf;
+    {
+        const float vf = (float)q0;
+        tvx2 = vf + vf;
+        tP = column_value_sq_seeded(((unsigned long long)db.y << 32) | db.x, (int)db.z, (int)db.w, lane, y) + vf * vf;
+    }
     float4 u = make_float4(0.f, 0.f, 0.f, 0.f);
     int cnt = 0;   // entries below the top (indices 0..cnt-1); [base, cnt) in the LDS ring, [0, base) in HBM
     int base = 0;
     auto evict = [&]() {
-        const float4 e = ring[base & (kRing - 1)][tid];
-        ent[base] = EnvEntry{(int)e.x >> 1, e.y, e.z};
+        ent[base] = to_mem(ring[base & (kRing - 1)][tid]);
         ++base;
     };
     const int qlo = q0 + 1, qhi = ql;
     if (qlo <= qhi) {
         const int wlo = qlo >> 6, whi = qhi >> 6;
         for (int wd = wlo; wd <= whi; ++wd) {
-            // Lane j holds the descriptor of column 64 wd + j; a column's fields are read with v_readlane.  Loaded and waited
-            // for here, once per 64 columns, and not prefetched across words: a load still pending over the column loop makes
-            // the compiler wait for (nearly) all memory operations at every column, i.e. for the spill stores.
-            const uint4 dcur = dp[min(wd * 64 + lane, W - 1)];
-            asm volatile("; descriptors %0 %1 %2 %3 are complete here, before the column loop" ::"v"(dcur.x), "v"(dcur.y), "v"(dcur.z), "v"(dcur.w));
             unsigned long long mk = uni64(smask[wd]);  // columns without a seed in the slice never own a pixel: skipped
             if (wd == wlo) mk &= ~0ull << (qlo & 63);
             if (wd == whi) mk &= ~0ull >> (63 - (qhi & 63));
@@ -101,39 +107,35 @@ __device__ __forceinline__ void local_run(const uint4* __restrict__ dp, int W, c
                 const int j = __ffsll((long long)mk) - 1;
                 mk &= mk - 1ull;
                 const int q = wd * 64 + j;
-                uint4 dq;
-                dq.x = (unsigned)__builtin_amdgcn_readlane((int)dcur.x, j);
-                dq.y = (unsigned)__builtin_amdgcn_readlane((int)dcur.y, j);
-                dq.z = (unsigned)__builtin_amdgcn_readlane((int)dcur.z, j);
-                dq.w = (unsigned)__builtin_amdgcn_readlane((int)dcur.w, j);
+                // the column's descriptor: the same 16 bytes for every lane, so a scalar load into SGPRs (written out: left to
+                // itself the compiler fetches the seed word with a vector load and waits for every store in flight)
+                u32x4 dq;
+                asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dq) : "s"(dp + q) : "memory");
                 const float fq = column_value_sq_seeded(((unsigned long long)dq.y << 32) | dq.x, (int)dq.z, (int)dq.w, lane, y);
                 const float qf = (float)q;
-                const float q2 = qf * qf;  // rounds like the reference's float(long(q * q))
-                const float hq = fq + q2;
+                const float hq = fq + qf * qf;  // P of column q (q * q rounds like the reference's float(long(q * q)))
                 const float twoq = qf + qf;
                 float s;
                 unsigned long long any_pop;
                 // Test at the bottom: one taken branch per extra pass, none on the way out.  A lane that does not pop
                 // recomputes the same s in the passes other lanes still need.
                 do {
-                    // s = ((f[q] + q^2) - f[v] - v^2) / (2q - 2v), left to right in float (imgproc.h:111)
-                    const float N = (hq - tf) - tv2;
-                    s = envelope_quotient(N, twoq - tvx2);  // = N / (2q - 2v) bit for bit (fdcm_quotient.h)
+                    // s = ((f[q] + q^2) - f[v] - v^2) / (2q - 2v) (imgproc.h:111)
+                    s = envelope_quotient(hq - tP, twoq - tvx2);  // = N / (2q - 2v) bit for bit (fdcm_quotient.h)
                     // pop while s <= z[k]: the bottom entry's z is -inf and s is finite, so the bottom is never popped
                     const bool pop = s <= tz;
                     any_pop = __builtin_amdgcn_ballot_w64(pop);
                     if (pop) {
-                        tvx2 = u.x; tf = u.y; tz = u.z; tv2 = u.w;
+                        tvx2 = u.x; tP = u.y; tz = u.z;
                         --cnt;
                         if (cnt > 0) {
                             if (__builtin_expect(cnt == base, 0)) {  // ring empty: up to four spilled entries come back together
                                 // all four are written (the ring is empty; entries below 0 land in free slots): no load stays pending
                                 const EnvEntry e0 = ent[max(base - 1, 0)], e1 = ent[max(base - 2, 0)], e2 = ent[max(base - 3, 0)], e3 = ent[max(base - 4, 0)];
-                                const float v0 = (float)e0.v, v1 = (float)e1.v, v2 = (float)e2.v, v3 = (float)e3.v;
-                                ring[(base - 1) & (kRing - 1)][tid] = make_float4(v0 + v0, e0.f, e0.z, v0 * v0);
-                                ring[(base - 2) & (kRing - 1)][tid] = make_float4(v1 + v1, e1.f, e1.z, v1 * v1);
-                                ring[(base - 3) & (kRing - 1)][tid] = make_float4(v2 + v2, e2.f, e2.z, v2 * v2);
-                                ring[(base - 4) & (kRing - 1)][tid] = make_float4(v3 + v3, e3.f, e3.z, v3 * v3);
+                                ring[(base - 1) & (kRing - 1)][tid] = from_mem(e0);
+                                ring[(base - 2) & (kRing - 1)][tid] = from_mem(e1);
+                                ring[(base - 3) & (kRing - 1)][tid] = from_mem(e2);
+                                ring[(base - 4) & (kRing - 1)][tid] = from_mem(e3);
                                 base = max(base - 4, 0);
                             }
                             u = ring[(cnt - 1) & (kRing - 1)][tid];  // needed at the next pop at the earliest
@@ -141,24 +143,21 @@ __device__ __forceinline__ void local_run(const uint4* __restrict__ dp, int W, c
                     }
                 } while (any_pop != 0ull);
                 if (__builtin_expect(cnt - base == kRing, 0)) evict();
-                u = make_float4(tvx2, tf, tz, tv2);
+                u = make_float4(tvx2, tP, tz, 0.f);
                 ring[cnt & (kRing - 1)][tid] = u;
                 ++cnt;
-                tf = fq; tz = s; tv2 = q2; tvx2 = twoq;
+                tP = hq; tz = s; tvx2 = twoq;
             }
         }
     }
     // the top joins the entries; everything in the ring also goes to HBM (the ring keeps its content for the merge)
     if (cnt - base == kRing) evict();
-    ring[cnt & (kRing - 1)][tid] = make_float4(tvx2, tf, tz, tv2);
+    ring[cnt & (kRing - 1)][tid] = make_float4(tvx2, tP, tz, 0.f);
     ++cnt;
 #pragma unroll
     for (int e = 0; e < kRing; ++e) {
         const int i = base + e;
-        if (i < cnt) {
-            const float4 en = ring[i & (kRing - 1)][tid];
-            ent[i] = EnvEntry{(int)en.x >> 1, en.y, en.z};
-        }
+        if (i < cnt) ent[i] = to_mem(ring[i & (kRing - 1)][tid]);
     }
     // The merge looks at the 8 entries below a range's top first.  After a run of pops the ring holds fewer than that (it is
     // only refilled when empty): the missing ones come back from HBM now, all lanes and entries in one trip, instead of one
@@ -166,11 +165,9 @@ __device__ __forceinline__ void local_run(const uint4* __restrict__ dp, int W, c
     {
         const int want = max(cnt - kRing, 0);
         if (__builtin_amdgcn_ballot_w64(base > want) != 0ull) {
-            EnvEntry t0 = ent[max(base - 1, 0)], t1 = ent[max(base - 2, 0)], t2 = ent[max(base - 3, 0)], t3 = ent[max(base - 4, 0)],
-                     t4 = ent[max(base - 5, 0)], t5 = ent[max(base - 6, 0)], t6 = ent[max(base - 7, 0)];
-            auto put = [&](const EnvEntry& e, int idx) {
-                if (idx >= want) { const float vf = (float)e.v; ring[idx & (kRing - 1)][tid] = make_float4(vf + vf, e.f, e.z, vf * vf); }
-            };
+            const EnvEntry t0 = ent[max(base - 1, 0)], t1 = ent[max(base - 2, 0)], t2 = ent[max(base - 3, 0)], t3 = ent[max(base - 4, 0)],
+                           t4 = ent[max(base - 5, 0)], t5 = ent[max(base - 6, 0)], t6 = ent[max(base - 7, 0)];
+            auto put = [&](const EnvEntry& e, int idx) { if (idx >= want) ring[idx & (kRing - 1)][tid] = from_mem(e); };
             put(t0, base - 1); put(t1, base - 2); put(t2, base - 3); put(t3, base - 4); put(t4, base - 5); put(t5, base - 6); put(t6, base - 7);
             base = min(base, want);
         }
@@ -198,7 +195,7 @@ __device__ __forceinline__ void merge_bulk(SweepLds& L, int S, int row, int t, i
 #ifdef FDCM_LAB
     long long n_iter = 0, n_hbm = 0, n_refill = 0;
 #endif
-    // entry idx of (range seg, this row) as (2 v, f, z, v^2); from the LDS ring when it is still there, else from HBM
+    // entry idx of (range seg, this row) as (2 v, P = f + v^2, z); from the LDS ring when it is still there, else from HBM
     auto fetch = [&](int seg, int idx, int sbase, int sslot, bool need) -> float4 {
         float4 e = ring[idx & (kRing - 1)][seg * 64 + row];
         const bool hb = need && idx < sbase;
@@ -209,7 +206,7 @@ __device__ __forceinline__ void merge_bulk(SweepLds& L, int S, int row, int t, i
             const EnvEntry h = entr[sslot + idx];
             int hv; float hf, hz;
             asm volatile("v_mov_b32 %0, %3\n\tv_mov_b32 %1, %4\n\tv_mov_b32 %2, %5" : "=&v"(hv), "=&v"(hf), "=&v"(hz) : "v"(h.v), "v"(h.f), "v"(h.z));
-            if (hb) { const float vf = (float)hv; e = make_float4(vf + vf, hf, hz, vf * vf); }
+            if (hb) { const float vf = (float)hv; e = make_float4(vf + vf, hf + vf * vf, hz, 0.f); }
         }
         return e;
     };
@@ -272,7 +269,7 @@ __device__ __forceinline__ void merge_bulk(SweepLds& L, int S, int row, int t, i
             const bool valid = idx >= ms_lo;
             const float4 e = fetch(ms, max(idx, ms_lo), ms_base, ms_slot, valid && !done);
             // s = ((f[q] + q^2) - f[v] - v^2) / (2q - 2v), left to right in float (imgproc.h:111); pop while s <= z[k]
-            const float s = envelope_quotient((chq - e.y) - e.w, c2v - e.x);
+            const float s = envelope_quotient(chq - e.y, c2v - e.x);
             const bool pop = valid && s <= e.z;
             const unsigned m8 = (unsigned)(__builtin_amdgcn_ballot_w64(pop) >> sh) & 0xffu;
             const int npop = __builtin_ctz(~m8);  // leading pops, 0..8
@@ -296,14 +293,14 @@ __device__ __forceinline__ void merge_bulk(SweepLds& L, int S, int row, int t, i
             if (landed) { zc = ls; moves = nz <= zc; done = !moves; }
             if (__builtin_amdgcn_ballot_w64(moves) != 0ull) {
                 // ---- the entries behind it, 8 at once: entry cur + t + 1 pops entry cur + t if its local z <= the latter's quotient on the landing entry
-                const float l2v = __shfl(e.x, lsrc), lf = __shfl(e.y, lsrc), lv2 = __shfl(e.w, lsrc);
+                const float l2v = __shfl(e.x, lsrc), lP = __shfl(e.y, lsrc);
                 const int ci = cur - cb;             // window index of the incoming entry, 0..7
                 const int wi = ci + t, wn = wi + 1;  // .. of entry cur + t and of its successor (<= 15)
                 const int ksrc = sh + (wi & 7), nsrc = sh + (wn & 7);
                 const float kA2v = __shfl(A2v, ksrc), kAhq = __shfl(Ahq, ksrc), kB2v = __shfl(B2v, ksrc), kBhq = __shfl(Bhq, ksrc);
                 const float nAz = __shfl(Az, nsrc), nBz = __shfl(Bz, nsrc);
                 const float k2v = wi < 8 ? kA2v : kB2v, khq = wi < 8 ? kAhq : kBhq, nzk = wn < 8 ? nAz : nBz;
-                const float sk = t == 0 ? ls : envelope_quotient((khq - lf) - lv2, k2v - l2v);
+                const float sk = t == 0 ? ls : envelope_quotient(khq - lP, k2v - l2v);
                 const bool adv = moves && cur + t + 1 < nw && wn <= wend && nzk <= sk;
                 const unsigned a8 = (unsigned)(__builtin_amdgcn_ballot_w64(adv) >> sh) & 0xffu;
                 if (moves) cur += __builtin_ctz(~a8);  // (at least one: lane 0's test is the one that said so)
@@ -465,7 +462,7 @@ __device__ __forceinline__ void walk_batched(SweepLds& L, int W, int S, int part
 // ---- pure fill (imgproc.h:122-128) from the owner list; wave p of a block fills the pixels
 // [p * part_w, (p + 1) * part_w) of the block's 64 rows
 __device__ __forceinline__ void fill_part(SweepLds& L, float* __restrict__ vol, int W, int H, long k, int c, long chunk, int part_w, const SweepBuf& B, int p,
-                                          unsigned (*f_pk)[kNT], float (*f_b)[kNT]) {
+                                          int (*f_st)[kNT], float (*f_vf)[kNT], float (*f_b)[kNT]) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int y = c * 64 + lane;
     const size_t r = (size_t)chunk * 64 + lane;
@@ -476,15 +473,17 @@ __device__ __forceinline__ void fill_part(SweepLds& L, float* __restrict__ vol, 
     const int lc = L.s_lcount[lane];
     const OwnEntry* own = B.own + r * (size_t)B.lslots;
     // The fill writes the interleaved layout (ivol_index: 16 bytes = 4 neighbouring columns of one row) that the
-    // propagation reads: a lane collects the values of a group of 4 columns and stores them as one unit, 64 rows = 1 KB
-    // contiguous per wave.  Parts start on a group (part_w is a multiple of 4).
+    // propagation reads: a lane computes the values of a group of 4 columns and stores them as one unit, 64 rows = 1 KB
+    // contiguous per wave.  Parts start on a group (part_w is a multiple of 4) and rounds are whole groups.
     const size_t sl = ivol_slice_floats(W, H);
     const auto rs = __builtin_amdgcn_make_buffer_rsrc(vol + (size_t)k * sl, 0, (unsigned)(sl * 4), 0x00020000);
     const unsigned vrow = y < H ? (unsigned)y * 16u : 0x80000000u;  // rows past the image: dropped stores
     const int grpB = H * 16;
-    float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f;  // the group being collected (shift register: the newest value in g3)
-    while (qcur < qend) {
-        // entries [idx, idx + kRE) of every row go to LDS; the round ends where the first row would need entry idx + kRE
+    const int qend4 = (qend + 3) & ~3;  // the row's last group may be partial: its columns past W are padding and hold 0
+    while (qcur < qend4) {
+        // entries [idx, idx + kRE) of every row go to LDS as (first pixel, float(column), addend); the round ends where the
+        // first row would need entry idx + kRE -- and takes 4 pixels at least: an entry takes over at most once per pixel,
+        // so 4 pixels need 5 staged entries at most
         unsigned pk[kRE];
         float bb[kRE];
 #pragma unroll
@@ -495,43 +494,40 @@ __device__ __forceinline__ void fill_part(SweepLds& L, float* __restrict__ vol, 
 #pragma unroll
         for (int e = 0; e < kRE; ++e) {
             if (idx + e >= lc) pk[e] = 0x7fff0000u;  // past the list: never taken over
-            f_pk[e][tid] = pk[e]; f_b[e][tid] = bb[e];
+            f_st[e][tid] = (int)(pk[e] >> 16); f_vf[e][tid] = (float)(pk[e] & 0xffffu); f_b[e][tid] = bb[e];
         }
         const int lim = (int)(pk[kRE - 1] >> 16);
-        // (max: the lists the walk writes always allow progress; never spin on anything else)
-        const int qstop = max(qcur + 1, min(qend, __builtin_amdgcn_readfirstlane(wave_min(lim))));
-        unsigned cpk = pk[0], npk = pk[1];
-        float cb = bb[0], nb = bb[1];
+        const int qstop = max(qcur + 4, min(qend4, __builtin_amdgcn_readfirstlane(wave_min(lim))) & ~3);
+        float cvf = (float)(pk[0] & 0xffffu), cb = bb[0];
         int a = 0;
-        for (int q = qcur; q < qstop; ++q) {
-            const bool adv = q >= (int)(npk >> 16);
-            if (adv) { cpk = npk; cb = nb; ++a; }
-            npk = f_pk[a + 1][tid]; nb = f_b[a + 1][tid];  // a + 1 <= kRE - 1 because q < lim
-            const float dq = (float)(q - (int)(cpk & 0xffffu));  // dq * dq rounds like float(long(dq * dq))
-            g0 = g1; g1 = g2; g2 = g3; g3 = cb + dq * dq;
-            if ((q & 3) == 3) {  // wave-uniform
-                u32x4 out;
-                out.x = __float_as_uint(g0); out.y = __float_as_uint(g1); out.z = __float_as_uint(g2); out.w = __float_as_uint(g3);
-                // (the whole offset in the lane offset, none in the scalar operand: a 16-byte store reads its data late, and the
-                // compiler only inserts the wait state before the registers are overwritten when there is no scalar offset)
-                __builtin_amdgcn_raw_buffer_store_b128(out, rs, vrow + (unsigned)((q >> 2) * grpB), 0, 0);
+        for (int q0 = qcur; q0 < qstop; q0 += 4) {
+            float g[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                // the next entry takes over at its first pixel (a + 1 <= kRE - 1: see above)
+                const int nst = f_st[a + 1][tid];
+                const float nvf = f_vf[a + 1][tid], nb = f_b[a + 1][tid];
+                const bool adv = q0 + j >= nst;
+                cvf = adv ? nvf : cvf; cb = adv ? nb : cb; a += adv ? 1 : 0;
+                const float dq = (float)(q0 + j) - cvf;
+                // addend + (q - v)^2: integers below 2^24, so the fused form rounds nothing either (imgproc.h:127)
+                g[j] = q0 + j < W ? __builtin_fmaf(dq, dq, cb) : 0.f;
             }
+            u32x4 out;
+            out.x = __float_as_uint(g[0]); out.y = __float_as_uint(g[1]); out.z = __float_as_uint(g[2]); out.w = __float_as_uint(g[3]);
+            // (the whole offset in the lane offset, none in the scalar operand: a 16-byte store reads its data late, and the
+            // compiler only inserts the wait state before the registers are overwritten when there is no scalar offset)
+            __builtin_amdgcn_raw_buffer_store_b128(out, rs, vrow + (unsigned)((q0 >> 2) * grpB), 0, 0);
         }
         idx += a;
         qcur = qstop;
-    }
-    if (qend == W && (W & 3)) {  // the row's last group is partial: its columns past W are padding and hold 0
-        for (int q = W; q & 3; ++q) { g0 = g1; g1 = g2; g2 = g3; g3 = 0.f; }
-        u32x4 out;
-        out.x = __float_as_uint(g0); out.y = __float_as_uint(g1); out.z = __float_as_uint(g2); out.w = __float_as_uint(g3);
-        __builtin_amdgcn_raw_buffer_store_b128(out, rs, vrow + (unsigned)((W >> 2) * grpB), 0, 0);
     }
 }
 
 __global__ void __launch_bounds__(kNT) k_sweep_balanced(const ColDesc* __restrict__ desc, float* __restrict__ vol, int W, int H, int HW64, int part_w,
                                                         SweepBuf B) {
     // one LDS pool for the phases: the construction's rings (kept through the merge), the walk's lists, the fill's staging
-    constexpr size_t kPoolBytes = std::max({(size_t)kRing * kNT * sizeof(float4), (size_t)3 * 64 * kWinStride * 4, (size_t)2 * kRE * kNT * 4});
+    constexpr size_t kPoolBytes = std::max({(size_t)kRing * kNT * sizeof(float4), (size_t)3 * 64 * kWinStride * 4, (size_t)3 * kRE * kNT * 4});
     __shared__ SweepLds L;
     __shared__ float4 pool[kPoolBytes / sizeof(float4)];
     const long long t_start = wall_clock64();
@@ -610,7 +606,8 @@ __global__ void __launch_bounds__(kNT) k_sweep_balanced(const ColDesc* __restric
     if (tid == 0) B.cost[chunk] = (int)(wall_clock64() - t_start);
     {
         unsigned* w32 = reinterpret_cast<unsigned*>(pool);
-        fill_part(L, vol, W, H, k, c, chunk, part_w, B, wave, reinterpret_cast<unsigned(*)[kNT]>(w32), reinterpret_cast<float(*)[kNT]>(w32 + kRE * kNT));
+        fill_part(L, vol, W, H, k, c, chunk, part_w, B, wave, reinterpret_cast<int(*)[kNT]>(w32), reinterpret_cast<float(*)[kNT]>(w32 + kRE * kNT),
+                  reinterpret_cast<float(*)[kNT]>(w32 + 2 * kRE * kNT));
     }
     LAB_STAMP(7);
 #ifdef FDCM_LAB
@@ -656,7 +653,10 @@ void launch_sweep_balanced(hipStream_t st, const void* desc, float* vol, int W, 
         FDCM_HIP(hipMemsetAsync(labbuf.p, 0, nl * 8, st));
         SweepBuf B2 = B;
         B2.lab = labbuf.as<long long>();
-        hipLaunchKernelGGL(k_sweep_balanced, dim3((unsigned)nchunks), dim3(kNT), 0, st, (const ColDesc*)desc, vol, W, H, HW64, part_w, B2);
+        // FDCM_SWEEP_LAB=4: unused dynamic LDS on top, so that one workgroup has a CU to itself (what do co-resident waves cost?)
+        const size_t pad = atoi(getenv("FDCM_SWEEP_LAB")) == 4 ? 70000 : 0;
+        if (pad) FDCM_HIP(hipFuncSetAttribute((const void*)k_sweep_balanced, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad));
+        hipLaunchKernelGGL(k_sweep_balanced, dim3((unsigned)nchunks), dim3(kNT), pad, st, (const ColDesc*)desc, vol, W, H, HW64, part_w, B2);
         FDCM_HIP(hipStreamSynchronize(st));
         std::vector<long long> d(nl);
         FDCM_HIP(hipMemcpy(d.data(), labbuf.p, nl * 8, hipMemcpyDeviceToHost));
