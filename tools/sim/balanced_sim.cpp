@@ -34,7 +34,8 @@ int main(int argc, char** argv) {
     int32_t hdr[3];
     if (!fp || fread(hdr, 4, 3, fp) != 3) return 1;
     const int m = hdr[0], W = hdr[1], H = hdr[2];
-    const int Sarg = argc > 2 ? atoi(argv[2]) : 8, cpw = argc > 3 ? atoi(argv[3]) : 64, check = argc > 4 ? atoi(argv[4]) : 0;
+    const int Sarg = argc > 2 ? atoi(argv[2]) : 8, cpw = argc > 3 ? atoi(argv[3]) : 64, check = argc > 4 ? atoi(argv[4]) : 0, prune = argc > 5 ? atoi(argv[5]) : 0;
+    Dist kept_frac;
     std::vector<uint8_t> seed((size_t)W * H);
     Dist cur_adv, m_pops;
     Dist wave_passes, wave_cols, block_maxpass, depth_max, local_n, merge_tests_j, merge_tests_blk, valid_n, own_seg, own_row, segs, own_blk_maxseg, lit_passes;
@@ -57,13 +58,42 @@ int main(int argc, char** argv) {
         }
         for (int c0 = 0; c0 < H; c0 += 64) {
             const int R = std::min(64, H - c0);
+            // columns kept for this chunk: a column without a seed inside the chunk whose distance to the chunk is lb is pruned when
+            // anchors (columns with a seed inside the chunk, f <= 63^2 in every row) a1 < u < a2 exist with lb^2 >= 63^2 + ((a2 - a1) / 2)^2:
+            // its point lies on or above the chord of the anchors in every row, so it owns no pixel
+            std::vector<int> kept;
+            if (prune) {
+                std::vector<char> anchor(n, 0);
+                std::vector<long> lb(n, 0);
+                for (int j = 0; j < n; ++j) {
+                    const uint8_t* cc = &seed[(size_t)cols[j] * H];
+                    bool in = false; for (int y = c0; y < c0 + R; ++y) in |= cc[y] != 0;
+                    anchor[j] = in;
+                    if (!in) { long up = 1 << 20, dn = 1 << 20; for (int y = c0 - 1; y >= 0; --y) if (cc[y]) { up = c0 - y; break; } for (int y = c0 + R; y < H; ++y) if (cc[y]) { dn = y - (c0 + R - 1); break; } lb[j] = std::min(up, dn); }
+                }
+                std::vector<int> prevA(n, -1), nextA(n, -1);
+                int last = -1; for (int j = 0; j < n; ++j) { prevA[j] = last; if (anchor[j]) last = j; }
+                last = -1; for (int j = n - 1; j >= 0; --j) { nextA[j] = last; if (anchor[j]) last = j; }
+                for (int j = 0; j < n; ++j) {
+                    bool drop = false;
+                    if (!anchor[j] && prevA[j] >= 0 && nextA[j] >= 0) {
+                        const long d = cols[nextA[j]] - cols[prevA[j]];
+                        drop = 4 * lb[j] * lb[j] >= 4 * 3969 + d * d;
+                    }
+                    if (!drop) kept.push_back(j);
+                }
+            } else for (int j = 0; j < n; ++j) kept.push_back(j);
+            kept_frac.add((long)(1000.0 * kept.size() / n));
+            const int nk = (int)kept.size();
             std::vector<std::vector<std::vector<Ent>>> st(S, std::vector<std::vector<Ent>>(R));  // local stacks [segment][row]
             long blk_max = 0;
             for (int w = 0; w < S; ++w) {
-                const int j0 = (int)((long)n * w / S), j1 = (int)((long)n * (w + 1) / S);  // columns [j0, j1)
+                const int k0 = (int)((long)nk * w / S), k1 = (int)((long)nk * (w + 1) / S);  // kept columns [k0, k1)
+                if (k0 >= k1) { wave_passes.add(0); wave_cols.add(0); depth_max.add(0); local_n.add(0); for (int r = 0; r < R; ++r) st[w][r].clear(); continue; }
+                const int j0 = kept[k0], j1 = 0; (void)j1;
                 long passes = 0, dmax = 0;
                 for (int r = 0; r < R; ++r) st[w][r].push_back(Ent{cols[j0], f[(size_t)j0 * H + c0 + r], -INFINITY});
-                for (int j = j0 + 1; j < j1; ++j) {
+                for (int kk = k0 + 1; kk < k1; ++kk) { const int j = kept[kk];
                     int mx = 0;
                     for (int r = 0; r < R; ++r) {
                         auto& s = st[w][r];
@@ -77,7 +107,7 @@ int main(int argc, char** argv) {
                     }
                     passes += mx;
                 }
-                wave_passes.add(passes); wave_cols.add(j1 - j0); depth_max.add(dmax);
+                wave_passes.add(passes); wave_cols.add(k1 - k0); depth_max.add(dmax);
                 blk_max = std::max(blk_max, passes);
                 long ln = 0; for (int r = 0; r < R; ++r) ln = std::max(ln, (long)st[w][r].size());
                 local_n.add(ln);
@@ -105,10 +135,12 @@ int main(int argc, char** argv) {
                 std::vector<long> jt(S, 0);
                 std::vector<long> ownmaxseg(S, 0);
                 for (int r = 0; r < R; ++r) {
-                    std::vector<Ent> M = st[0][r];
-                    std::vector<int> segof(M.size(), 0);
-                    for (int w = 1; w < S; ++w) {
+                    int w0 = 0; while (st[w0][r].empty()) ++w0;
+                    std::vector<Ent> M = st[w0][r];
+                    std::vector<int> segof(M.size(), w0);
+                    for (int w = w0 + 1; w < S; ++w) {
                         const auto& B = st[w][r];
+                        if (B.empty()) continue;
                         long tests = 0, pops = 0;
                         size_t cur = 0;
                         float zc;
@@ -151,6 +183,7 @@ int main(int argc, char** argv) {
         fprintf(stderr, "slice %d: %d seeded columns, %d segments\n", k, n, S);
     }
     printf("%d x %d x %d, S = %d (cpw %d)\n", m, W, H, Sarg, cpw);
+    kept_frac.print("chunk: kept columns (permille)");
     segs.print("segments per slice");
     lit_passes.print("one wave per chunk: passes");
     wave_passes.print("wave: test passes");
