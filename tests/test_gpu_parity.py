@@ -867,6 +867,34 @@ def test_sizes_around_the_descriptor_tiles(amd, size):
         assert_volume_equal(dev, orc, f"size {size} distance {dist}")
 
 
+@pytest.mark.parametrize("size,kind", [(2896, "far corners"), (2897, "far corners"), (2896, "dense"), (2895, "one line"), (2890, "empty slices")])
+def test_sizes_at_the_exact_integer_bound(amd, size, kind):
+    """The balanced L2 sweep runs where every value of the reference's pass is an exact integer in float (W^2 + H^2 <= 2^24,
+    i.e. up to 2896 px); 2897 takes the literal kernel.  Scenes that push the values to the bound: seeds only in two
+    opposite corners (squared distances up to 2895^2 in pass 1 and numerators close to 2^24 in pass 2), a dense scene,
+    a single line (every other orientation slice has no seed at all: FLT_MAX everywhere), few lines at depth 9 (mostly
+    seedless slices, slices with a handful of columns).  Whole volume, L2 and L2^2, against the oracle."""
+    from openfdcm_amd.engine import DeviceFeatureMap
+    rng = np.random.default_rng(size + len(kind))
+    a, b = 0.0, float(size - 1)
+    if kind == "far corners":
+        lines, depth = [[a, a, 9, 4], [b, b, b - 6, b - 11], [a + 3, a + 20, a + 30, a + 2], [b - 40, b - 2, b - 3, b - 25]], 3
+    elif kind == "dense":
+        pts = rng.uniform(0, size - 1, size=(400, 4)).astype(np.float32)
+        pts[0], pts[1] = [a, a, 5, 3], [b, b, b - 7, b - 4]
+        lines, depth = pts.tolist(), 2
+    elif kind == "one line":
+        lines, depth = [[a, a, 700, 260], [b, b, b, b]], 4  # (the zero-length line only pins the size)
+    else:
+        lines, depth = [[a, a, 300, 5], [b, b, b - 100, b - 330], [1500, 20, 1510, 2800]], 9
+    scene = np.ascontiguousarray(np.array(lines, dtype=np.float32).T)
+    for dist in (0, 1):
+        dev = DeviceFeatureMap.build(scene, depth=depth, coeff=5.0, padding=1.0, distance=dist)
+        orc = O.build(scene, depth=depth, coeff=5.0, padding=1.0, distance=dist, nthreads=8)
+        assert dev.volume().shape[1] == size
+        assert_volume_equal(dev, orc, f"size {size} ({kind}) distance {dist}")
+
+
 @pytest.mark.parametrize("size", [63, 65, 130, 5000])
 def test_l1_single_pass_sizes(amd, size):
     """The L1 transform as one pass over the volume (per-word minima, carries over the words of a row, word by word): one
