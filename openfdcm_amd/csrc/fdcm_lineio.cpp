@@ -40,7 +40,8 @@ void lines_read(const char* path, float** out, int64_t* n_out) {
     if (blob.size() < 39 || std::memcmp(blob.data(), kSignature, 16) != 0) throw std::string("File '") + path + "' is not an OPENFDCM line file";
     const bool compressed = blob[22] != 0;
     const uint64_t ulen = get<uint64_t>(&blob[23]), clen = get<uint64_t>(&blob[31]);
-    if (clen > blob.size() - 39 || ulen > (1ull << 40)) throw std::string("File '") + path + "' is truncated";
+    // (a deflate stream expands by at most 1032 : 1: a header that claims more is not worth an allocation)
+    if (clen > blob.size() - 39 || ulen > clen * 1032ull + 65536ull) throw std::string("File '") + path + "' is truncated";
     std::vector<unsigned char> body;
     if (compressed) {
         body.resize((size_t)ulen);
