@@ -9,8 +9,8 @@
 // literal pass on the BASELINE scenes and on random / near-degenerate columns):
 //   (1) for an integer pixel q <= W - 1 < 2^12:  q <= RN(N / D)  <=>  q <= N / D   (q - N / D is 0 or at least 1 / D, far
 //       above half an ulp of q), so the fill's `while (z[k + 1] < q)` (:124) classifies pixels as exact arithmetic would;
-//   (2) the float construction pops at least what the exact one pops, and a vertex it pops in addition has an exact
-//       region narrower than an ulp: it owns no pixel.
+//   (2) a stack the float construction keeps has strictly increasing z, hence strictly increasing exact intersections:
+//       it is an exactly convex chain, and by (1) the pixels it hands its entries are those of exact arithmetic.
 //   => the owner of every pixel in the reference's run is the EXACT owner: the seeded column u minimising
 //      f[u] + (q - u)^2 over the integers, the smallest u on a tie.  The same holds for the reference's construction run on
 //      ANY subset of the columns that contains those owners.
@@ -25,8 +25,8 @@
 // One workgroup per (slice, 64-row chunk), kSeg waves, lane = row:
 //   local run   wave w: the literal construction over its columns; stack = top entry in registers + a ring of kRing
 //               entries per row in LDS + HBM scratch behind it (row-major); everything also lands in HBM for the walk
-//   merge       wave 0: per row, the junctions from left to right; entries come from the LDS rings (HBM behind them)
-//   owner walk  all waves, 64 / kSeg rows each: one walk over the merged stack of a row -> owner list
+//   merge       8 rows per wave, 8 lanes per row: the junctions from left to right, 8 entries per step (rings, HBM behind)
+//   owner walk  same layout: 8 stack entries of a row per step -> owner list (addend chains by pointer doubling)
 //   fill        all waves, W / kSeg pixels each, 16-byte units of the interleaved layout [k][x/4][y][x%4]
 #include <algorithm>
 #include <cstdio>
