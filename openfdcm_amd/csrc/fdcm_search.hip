@@ -72,6 +72,9 @@ struct SearchParams {
     int* flags;
     int* evals;
     unsigned long long* counters;  // [0] translations evaluated by the rule, [1] unused, [2] matches
+#ifdef FDCM_LAB
+    unsigned long long* lab;  // 8 stamps per candidate (make LAB=1, FDCM_SEARCH_LAB=1)
+#endif
 };
 
 static constexpr int kWavesPerBlock = 4;
@@ -86,7 +89,15 @@ struct OptState {
     unsigned H;
     float tx, ty, savx, savy;
     int lim_p, lim_n;  // multiplier limits: 32 bits are enough, see k_search
+#ifdef FDCM_LAB
+    unsigned long long* lab;
+#endif
 };
+#ifdef FDCM_LAB
+#define SEARCH_STAMP(ptr, i) do { if ((ptr) && (threadIdx.x & 63) == 0) (ptr)[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SEARCH_STAMP(ptr, i) do {} while (0)
+#endif
 
 // Score multipliers k_from, k_from + dir, ... (cnt of them) into sc[dst ..]; with_zero additionally
 // scores translation (0,0) into sc[2 WIN].  32 translations per gather round.
@@ -131,6 +142,7 @@ __device__ __forceinline__ void optimise(const OptState& o, float& best, int& be
         score_range<BUF32>(o, -1, -1, have_n, WIN, false);
     }
     const float init = o.sc[2 * WIN];
+    SEARCH_STAMP(o.lab, 3);
     n_eval += 1;
     best = init;
     float back = init;  // scores.back(): NOT reset between the two directions (batchoptimize.cpp:73)
@@ -364,6 +376,10 @@ __global__ void __launch_bounds__(256, FDCM_SEARCH_WPE) k_search(const SearchPar
     float* sc = L + 5 * P.lds_lines;
     for (int i = lane; i < P.m; i += 64) s_keys[i] = P.keys[i];
     const long long cand = P.cand_offsets[t] + local;
+#ifdef FDCM_LAB
+    unsigned long long* lab = P.lab ? P.lab + 8 * cand : nullptr;
+    if (lab && lane == 0) { lab[0] = __builtin_amdgcn_s_memtime(); lab[6] = wall_clock64(); }
+#endif
     const VolRef V = make_volref(P.vol, ivol_slice_floats(P.W, P.H), P.m, BUF32);
 
     // ---- which candidate: sorted template line j, window slot wi, alignment flip
@@ -374,6 +390,9 @@ __global__ void __launch_bounds__(256, FDCM_SEARCH_WPE) k_search(const SearchPar
 #pragma unroll
     for (int c = 0; c < 4; ++c) { tl[c] = P.tlines[(l0 + tl_local) * 4 + c]; sl[c] = P.slines[(size_t)scene_idx * 4 + c]; }
     const float* s_tl = P.tlines + l0 * 4;  // template lines straight from HBM (coalesced 16 B per lane)
+#ifdef FDCM_LAB
+    if (lab && tl[0] + sl[0] != 1.2345e-30f) SEARCH_STAMP(lab, 1);
+#endif
     // align + transform, defaultmatch.cpp:59-67
     float T1[6], T2[6], T[6];
     align_pair(tl, sl, T1, T2);
@@ -397,6 +416,9 @@ __global__ void __launch_bounds__(256, FDCM_SEARCH_WPE) k_search(const SearchPar
         mny = std_min(mny, std_min(y1, y2)); mxy = std_max(mxy, std_max(y1, y2));
     }
     mnx = wave_min_f(mnx); mny = wave_min_f(mny); mxx = wave_max_f(mxx); mxy = wave_max_f(mxy);
+#ifdef FDCM_LAB
+    if (lab && mnx != 1.2345e-30f) SEARCH_STAMP(lab, 2);
+#endif
 
     // ---- optimize<BatchOptimize / DefaultOptimize> for this candidate
     bool valid = true;
@@ -419,6 +441,9 @@ __global__ void __launch_bounds__(256, FDCM_SEARCH_WPE) k_search(const SearchPar
         OptState o;
         o.V = V; o.L = L; o.sc = sc; o.n_t = n_t; o.H = (unsigned)P.H; o.tx = P.tx; o.ty = P.ty;
         o.savx = savx; o.savy = savy; o.lane = lane;
+#ifdef FDCM_LAB
+        o.lab = lab;
+#endif
         o.B = P.optimizer == FDCM_BATCH_OPTIMIZE ? P.batch : 1; o.WIN = P.win; o.batch_rule = P.optimizer == FDCM_BATCH_OPTIMIZE;
         o.reset_back = P.optimizer == FDCM_INDULGENT_OPTIMIZE;
         // static_cast<long>(max_mul / min_mul), batchoptimize.cpp:51,74
@@ -444,6 +469,9 @@ __global__ void __launch_bounds__(256, FDCM_SEARCH_WPE) k_search(const SearchPar
         // translations the reference's rule evaluated (reduced by the compaction kernels: one
         // contended atomic per candidate would serialise the whole grid at ~12 ns each)
         P.evals[cand] = (int)n_eval;
+#ifdef FDCM_LAB
+        if (lab) { lab[4] = __builtin_amdgcn_s_memtime(); lab[7] = wall_clock64(); lab[5] = (unsigned long long)n_eval; }
+#endif
     }
 }
 
@@ -735,8 +763,34 @@ void run_search(fdcm_featuremap* fm, const fdcm_templates* t, const float* scene
         FDCM_HIP(hipMemcpyAsync(fm->s_bins.p, hb, (size_t)ncand * stride * sizeof(unsigned short), hipMemcpyHostToDevice, st));
         P.host_bins = fm->s_bins.as<unsigned short>();
     }
+#ifdef FDCM_LAB
+    static const bool env_lab = getenv("FDCM_SEARCH_LAB") != nullptr;
+    static DevBuf labbuf;
+    P.lab = nullptr;
+    if (env_lab) { labbuf.reserve((size_t)ncand * 64); FDCM_HIP(hipMemsetAsync(labbuf.p, 0, (size_t)ncand * 64, st)); P.lab = labbuf.as<unsigned long long>(); }
+#endif
     if (buf32) hipLaunchKernelGGL(k_search<true>, dim3((unsigned)P.nblocks), dim3(256), lds, st, P);
     else hipLaunchKernelGGL(k_search<false>, dim3((unsigned)P.nblocks), dim3(256), lds, st, P);
+#ifdef FDCM_LAB
+    if (env_lab) {
+        FDCM_HIP(hipStreamSynchronize(st));
+        std::vector<unsigned long long> h((size_t)ncand * 8);
+        FDCM_HIP(hipMemcpy(h.data(), labbuf.p, h.size() * 8, hipMemcpyDeviceToHost));
+        double d[4] = {0, 0, 0, 0}, life = 0, ev = 0;
+        unsigned long long w0 = ~0ull, w1 = 0;
+        long long n = 0;
+        for (long long c = 0; c < ncand; ++c) {
+            const unsigned long long* e = &h[(size_t)c * 8];
+            if (!e[4] || !e[3]) continue;
+            d[0] += (double)(e[1] - e[0]); d[1] += (double)(e[2] - e[1]); d[2] += (double)(e[3] - e[2]); d[3] += (double)(e[4] - e[3]);
+            life += (double)(e[7] - e[6]); ev += (double)e[5];
+            w0 = std::min(w0, e[6]); w1 = std::max(w1, e[7]);
+            ++n;
+        }
+        if (n) fprintf(stderr, "[search lab] %lld waves: loads %.0f  lines+bins %.0f  round1 %.0f  rule+rounds %.0f cycles; life %.2f us (100 MHz clock), span %.1f us, evals/wave %.1f\n",
+                       n, d[0] / n, d[1] / n, d[2] / n, d[3] / n, life / n / 100.0, (double)(w1 - w0) / 100.0, ev / n);
+    }
+#endif
     fdcm_match* dst = out_device;
     if (!dst) {
         // host output: one extra record behind the candidates' capacity carries the counters, so that the

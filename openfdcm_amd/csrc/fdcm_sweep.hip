@@ -722,6 +722,14 @@ void launch_sweep_balanced(hipStream_t st, const void* desc, float* vol, int W, 
         }
         return;
     }
+    // FDCM_SWEEP_PAD=<bytes>: unused dynamic LDS on every workgroup, no other change (how does a pipeline of frames react to
+    // fewer sweeps per CU?)
+    static const int env_pad = getenv("FDCM_SWEEP_PAD") ? atoi(getenv("FDCM_SWEEP_PAD")) : 0;
+    if (env_pad > 0) {
+        FDCM_HIP(hipFuncSetAttribute((const void*)k_sweep_balanced, hipFuncAttributeMaxDynamicSharedMemorySize, env_pad));
+        hipLaunchKernelGGL(k_sweep_balanced, dim3((unsigned)nchunks), dim3(kNT), (size_t)env_pad, st, (const ColDesc*)desc, vol, W, H, HW64, part_w, B);
+        return;
+    }
 #endif
     hipLaunchKernelGGL(k_sweep_balanced, dim3((unsigned)nchunks), dim3(kNT), 0, st, (const ColDesc*)desc, vol, W, H, HW64, part_w, B);
 }
