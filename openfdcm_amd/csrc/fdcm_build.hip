@@ -747,6 +747,9 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after) {
         hipLaunchKernelGGL(k_l1_carries, dim3((unsigned)(((long)m * HW64 * 64 + 255) / 256)), dim3(256), 0, st, mins, nwords, (long)m * HW64 * 64);
         hipLaunchKernelGGL(k_l1_word, dim3((unsigned)((wwaves + 3) / 4)), dim3(256), 0, st, d_desc, (const float2*)mins, vol, W, H, HW64, nwords, wwaves);
     } else if (balanced) {
+#ifdef FDCM_LAB
+        if (!lab_skip("sweep"))
+#endif
         launch_sweep_balanced(st, d_desc, vol, W, H, HW64, nchunks, sb);
     } else {
         launch_sweep_literal(st, d_desc, vol, W, H, HW64, nchunks, fm->stack.p);
@@ -759,6 +762,9 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after) {
         float* ivol = fm->ivol.as<float>();
         const unsigned pblocks = (unsigned)((nq + 255) / 256);
         const int sq = (want_sqrt ? 1 : 0) | (fm->vol1_interleaved ? 2 : 0);
+#ifdef FDCM_LAB
+        if (lab_skip("propagate")) {} else
+#endif
         if (m == 30) hipLaunchKernelGGL(k_propagate_reg<30>, dim3(pblocks), dim3(256), 0, st, (const float*)vol, ivol, W, H, d_prop, sq);
         else if (m == 60) hipLaunchKernelGGL(k_propagate_reg<60>, dim3(pblocks), dim3(256), 0, st, (const float*)vol, ivol, W, H, d_prop, sq);
         else if (m == 90) hipLaunchKernelGGL(k_propagate_reg<90>, dim3(pblocks), dim3(256), 0, st, (const float*)vol, ivol, W, H, d_prop, sq);
@@ -814,6 +820,9 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after) {
             hipLaunchKernelGGL(k_integral<XC>, igrid, dim3(256), lds, st, (const float*)fm->ivol.as<float>(), vol, W, H, d_int,  \
                                d_tab, shw, kstride);                                                               \
         } while (0)
+#ifdef FDCM_LAB
+        if (lab_skip("integral")) {} else
+#endif
         if (xc == 256) FDCM_INTEGRAL(256); else if (xc == 128) FDCM_INTEGRAL(128); else FDCM_INTEGRAL(64);
 #undef FDCM_INTEGRAL
     }

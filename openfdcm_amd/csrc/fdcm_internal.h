@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstdlib>
+#include <cstring>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -214,4 +216,11 @@ int device_cus(int device);
 // pooled pinned host buffers for match arrays returned to the caller (fdcm_host.cpp)
 fdcm_match* result_acquire(size_t bytes);
 void result_release(fdcm_match* m);
+#ifdef FDCM_LAB
+// lab build: FDCM_LAB_SKIP=sweep,search,.. leaves the named kernels out of every frame (what does each cost the pipeline?)
+inline bool lab_skip(const char* what) {
+    const char* e = getenv("FDCM_LAB_SKIP");
+    return e && std::strstr(e, what) != nullptr;
+}
+#endif
 }  // namespace fdcm

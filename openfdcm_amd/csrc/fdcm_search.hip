@@ -77,7 +77,10 @@ struct SearchParams {
 #endif
 };
 
-static constexpr int kWavesPerBlock = 4;
+#ifndef FDCM_SEARCH_WPB
+#define FDCM_SEARCH_WPB 4
+#endif
+static constexpr int kWavesPerBlock = FDCM_SEARCH_WPB;
 
 struct OptState {
     VolRef V;        // the integrated volume
@@ -347,7 +350,7 @@ __global__ void __launch_bounds__(1024) k_wl_scatter(const SearchParams P, long 
 #define FDCM_SEARCH_WPE 4
 #endif
 template <bool BUF32>
-__global__ void __launch_bounds__(256, FDCM_SEARCH_WPE) k_search(const SearchParams P) {
+__global__ void __launch_bounds__(64 * kWavesPerBlock, FDCM_SEARCH_WPE) k_search(const SearchParams P) {
     extern __shared__ float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int t, local;
@@ -768,9 +771,10 @@ void run_search(fdcm_featuremap* fm, const fdcm_templates* t, const float* scene
     static DevBuf labbuf;
     P.lab = nullptr;
     if (env_lab) { labbuf.reserve((size_t)ncand * 64); FDCM_HIP(hipMemsetAsync(labbuf.p, 0, (size_t)ncand * 64, st)); P.lab = labbuf.as<unsigned long long>(); }
+    if (lab_skip("search")) {} else
 #endif
-    if (buf32) hipLaunchKernelGGL(k_search<true>, dim3((unsigned)P.nblocks), dim3(256), lds, st, P);
-    else hipLaunchKernelGGL(k_search<false>, dim3((unsigned)P.nblocks), dim3(256), lds, st, P);
+    if (buf32) hipLaunchKernelGGL(k_search<true>, dim3((unsigned)P.nblocks), dim3(64 * kWavesPerBlock), lds, st, P);
+    else hipLaunchKernelGGL(k_search<false>, dim3((unsigned)P.nblocks), dim3(64 * kWavesPerBlock), lds, st, P);
 #ifdef FDCM_LAB
     if (env_lab) {
         FDCM_HIP(hipStreamSynchronize(st));
