@@ -89,13 +89,16 @@ __device__ __forceinline__ void local_run(const uint4* __restrict__ dp, int W, c
         tvx2 = vf + vf;
         tP = column_value_sq_seeded(((unsigned long long)db.y << 32) | db.x, (int)db.z, (int)db.w, lane, y) + vf * vf;
     }
-    float4 u = make_float4(0.f, 0.f, 0.f, 0.f);
+    // u = (uv, up, uz): register copy of ring entry cnt - 1 (a single pop needs no LDS round trip)
+    float uv = 0.f, up = 0.f, uz = 0.f;
     int cnt = 0;   // entries below the top (indices 0..cnt-1); [base, cnt) in the LDS ring, [0, base) in HBM
     int base = 0;
     auto evict = [&]() {
         ent[base] = to_mem(ring[base & (kRing - 1)][tid]);
         ++base;
     };
+    const unsigned lanebase = (unsigned)(size_t)&ring[0][tid];  // LDS byte address of this lane's ring entry 0 (entry i: + i * 8192)
+    static_assert(kNT * sizeof(float4) == 8192, "the pop loop below shifts the ring index by 13");
     const int qlo = q0 + 1, qhi = ql;
     if (qlo <= qhi) {
         const int wlo = qlo >> 6, whi = qhi >> 6;
@@ -116,20 +119,62 @@ __device__ __forceinline__ void local_run(const uint4* __restrict__ dp, int W, c
                 const float hq = fq + qf * qf;  // P of column q (q * q rounds like the reference's float(long(q * q)))
                 const float twoq = qf + qf;
                 float s;
-                unsigned long long any_pop;
-                // Test at the bottom: one taken branch per extra pass, none on the way out.  A lane that does not pop
-                // recomputes the same s in the passes other lanes still need.
+                // The pop loop, written out and without exec masks.  s = ((f[q] + q^2) - f[v] - v^2) / (2q - 2v) (imgproc.h:111)
+                // by envelope_quotient's four instructions (fdcm_quotient.h); pop while s <= z[k] (the bottom entry's z is -inf
+                // and s is finite, so the bottom is never popped); the wave repeats the pass while any lane pops (a lane that
+                // does not recomputes the same s).  A pop is four selects from the register copy u; then EVERY lane reads the
+                // entry below its top from the ring again (for a lane that kept its top that is the u it holds), and the read
+                // is only waited for at the next pass's selects, behind its quotient.  One scalar round trip per pass (does any
+                // lane pop?) plus the test for the rare refill, placed behind the reads.
+                // The loop leaves with flag = 1 when a popping lane's ring ran empty above the stack's bottom (0 < cnt == base after
+                // the pop): those lanes have pend = 1, took their pop, and get their refill and u below.
+                int flag;
                 do {
-                    // s = ((f[q] + q^2) - f[v] - v^2) / (2q - 2v) (imgproc.h:111)
-                    s = envelope_quotient(hq - tP, twoq - tvx2);  // = N / (2q - 2v) bit for bit (fdcm_quotient.h)
-                    // pop while s <= z[k]: the bottom entry's z is -inf and s is finite, so the bottom is never popped
-                    const bool pop = s <= tz;
-                    any_pop = __builtin_amdgcn_ballot_w64(pop);
-                    if (pop) {
-                        tvx2 = u.x; tP = u.y; tz = u.z;
-                        --cnt;
-                        if (cnt > 0) {
-                            if (__builtin_expect(cnt == base, 0)) {  // ring empty: up to four spilled entries come back together
+                    int pend, c1;
+                    unsigned long long sx, sy;
+                    float qd, qn, qr, qe;
+                    unsigned ua;
+                    asm volatile(
+                        "s_mov_b32 %[flag], 0\n\t"
+                        "v_mov_b32 %[pend], 0\n"
+                        "L_fdcm_pop_%=:\n\t"
+                        "v_sub_f32 %[qd], %[twoq], %[tv]\n\t"
+                        "v_sub_f32 %[qn], %[hq], %[tp]\n\t"
+                        "v_rcp_f32 %[qr], %[qd]\n\t"
+                        "v_add_u32 %[c1], -1, %[cnt]\n\t"
+                        "v_mul_f32 %[s], %[qn], %[qr]\n\t"
+                        "v_fma_f32 %[qe], -%[qd], %[s], %[qn]\n\t"
+                        "v_fmac_f32 %[s], %[qe], %[qr]\n\t"
+                        "v_cmp_le_f32 vcc, %[s], %[tz]\n\t"
+                        "s_cbranch_vccz L_fdcm_done_%=\n\t"
+                        "s_waitcnt lgkmcnt(0)\n\t"
+                        "v_cndmask_b32 %[tv], %[tv], %[uv], vcc\n\t"
+                        "v_cndmask_b32 %[tp], %[tp], %[up], vcc\n\t"
+                        "v_cndmask_b32 %[tz], %[tz], %[uz], vcc\n\t"
+                        "v_cndmask_b32 %[cnt], %[cnt], %[c1], vcc\n\t"
+                        "v_add_u32 %[ua], -1, %[cnt]\n\t"
+                        "v_cmp_eq_u32 %[sx], %[cnt], %[base]\n\t"
+                        "v_cmp_lt_i32 %[sy], 0, %[cnt]\n\t"
+                        "v_and_b32 %[ua], 7, %[ua]\n\t"
+                        "v_lshl_add_u32 %[ua], %[ua], 13, %[lb]\n\t"
+                        "ds_read_b32 %[uv], %[ua]\n\t"
+                        "ds_read_b32 %[up], %[ua] offset:4\n\t"
+                        "ds_read_b32 %[uz], %[ua] offset:8\n\t"
+                        "s_and_b64 %[sx], %[sx], %[sy]\n\t"
+                        "s_and_b64 %[sx], %[sx], vcc\n\t"
+                        "s_cbranch_scc0 L_fdcm_pop_%=\n\t"
+                        "v_cndmask_b32 %[pend], 0, 1, %[sx]\n\t"
+                        "s_mov_b32 %[flag], 1\n"
+                        "L_fdcm_done_%=:\n\t"
+                        "s_waitcnt lgkmcnt(0)"
+                        : [s] "=&v"(s), [tv] "+v"(tvx2), [tp] "+v"(tP), [tz] "+v"(tz), [uv] "+v"(uv), [up] "+v"(up), [uz] "+v"(uz), [cnt] "+v"(cnt),
+                          [pend] "=&v"(pend), [flag] "=&s"(flag), [sx] "=&s"(sx), [sy] "=&s"(sy), [c1] "=&v"(c1), [qd] "=&v"(qd), [qn] "=&v"(qn), [qr] "=&v"(qr), [qe] "=&v"(qe),
+                          [ua] "=&v"(ua)
+                        : [twoq] "v"(twoq), [hq] "v"(hq), [base] "v"(base), [lb] "v"(lanebase)
+                        : "vcc", "scc", "memory");
+                    if (flag) {  // wave-uniform
+                        if (pend && cnt > 0) {
+                            if (cnt == base) {  // ring empty: up to four spilled entries come back together
                                 // all four are written (the ring is empty; entries below 0 land in free slots): no load stays pending
                                 const EnvEntry e0 = ent[max(base - 1, 0)], e1 = ent[max(base - 2, 0)], e2 = ent[max(base - 3, 0)], e3 = ent[max(base - 4, 0)];
                                 ring[(base - 1) & (kRing - 1)][tid] = from_mem(e0);
@@ -138,13 +183,14 @@ __device__ __forceinline__ void local_run(const uint4* __restrict__ dp, int W, c
                                 ring[(base - 4) & (kRing - 1)][tid] = from_mem(e3);
                                 base = max(base - 4, 0);
                             }
-                            u = ring[(cnt - 1) & (kRing - 1)][tid];  // needed at the next pop at the earliest
+                            const float4 e = ring[(cnt - 1) & (kRing - 1)][tid];
+                            uv = e.x; up = e.y; uz = e.z;
                         }
                     }
-                } while (any_pop != 0ull);
+                } while (flag);
                 if (__builtin_expect(cnt - base == kRing, 0)) evict();
-                u = make_float4(tvx2, tP, tz, 0.f);
-                ring[cnt & (kRing - 1)][tid] = u;
+                uv = tvx2; up = tP; uz = tz;
+                ring[cnt & (kRing - 1)][tid] = make_float4(tvx2, tP, tz, 0.f);
                 ++cnt;
                 tP = hq; tz = s; tvx2 = twoq;
             }
