@@ -90,7 +90,7 @@ __device__ __forceinline__ void desc_lane(const ColDesc& d, int j, unsigned long
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-struct EnvEntry { int v; float f; float z; };       // one stack entry (imgproc.h: v[k], f[v[k]], z[k])
+struct EnvEntry { float v2; float P; float z; };     // one stack entry (imgproc.h: v[k], f[v[k]], z[k]) as the sweep's tests use it: 2 v, f[v] + v^2, z
 struct OwnEntry { unsigned pk; float b; };          // (first pixel << 16 | column), addend
 
 __device__ __forceinline__ unsigned long long uni64(unsigned long long v) {

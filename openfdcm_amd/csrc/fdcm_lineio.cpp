@@ -58,7 +58,9 @@ void lines_read(const char* path, float** out, int64_t* n_out) {
     const uint16_t record_len = get<uint16_t>(&body[35]);
     const uint64_t n = get<uint64_t>(&body[37]);
     if (format != 0) throw std::string("Line data format not recognized, found <") + std::to_string(record_len) + ">";  // serialization.h:88-91
-    if (record_len != 16 || offset > body.size() || n > (body.size() - offset) / 16) throw std::string("File '") + path + "' is truncated";
+    // (the reference reads lineRecordNum * lineDataRecordLen bytes into 16-byte lines: only 16 is a well-formed file)
+    if (record_len != 16) throw std::string("File '") + path + "': unsupported line record length <" + std::to_string(record_len) + ">";
+    if (offset > body.size() || n > (body.size() - offset) / 16) throw std::string("File '") + path + "' is truncated";
     float* lines = (float*)std::malloc(n ? (size_t)n * 16 : 16);
     if (!lines) throw std::string("out of memory");
     std::memcpy(lines, &body[offset], (size_t)n * 16);

@@ -272,6 +272,7 @@ void start_workers(fdcm_sharded* s, int n_slots) {
 }
 
 int64_t submit_frame(fdcm_sharded* s, Job&& job) {
+    DeviceGuard guard;  // the loop below switches devices on the caller's thread (also restored when it throws)
     if (s->n_slots == 0) start_workers(s, 1);
     const size_t si = (size_t)(s->next_ticket % s->n_slots);
     if (s->slot_ticket[si] >= 0) throw std::string("every frame slot holds a frame that has not been waited for");

@@ -19,6 +19,7 @@ struct SweepBuf {
     const unsigned long long* colmask;    // [slice][(W + 63) / 64]: the slice's seeded columns (k_coldesc_tile)
     int min_cols;                         // seeded columns a range holds at least (set by the launcher)
 #ifdef FDCM_LAB
+    int lane_cursors;                     // lab builds: the local run with a column cursor per lane (FDCM_SWEEP_LOCAL=cursors)
     long long* lab;                       // lab builds (make LAB=1): 16 clock stamps / counters per (chunk, wave), or null
 #endif
 };

@@ -31,6 +31,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "fdcm_build_dev.h"
@@ -43,7 +44,30 @@ static constexpr int kSeg = kSweepSegments;  // waves per block = column ranges 
 static constexpr int kNT = 64 * kSeg;
 static constexpr int kRing = 8;      // stack entries per (row, range) below the top kept in LDS
 static constexpr int kRE = 10;       // owner entries per row and round of the fill (three words each in LDS)
+[[maybe_unused]] static constexpr int kLabN = 24;     // lab builds: 64-bit words per (chunk, wave) record
 static constexpr int kMinCols = 16;  // a range holds at least this many seeded columns (fewer ranges on small slices); FDCM_SWEEP_MINCOLS
+[[maybe_unused]] static constexpr int kCW = 8;        // lab: columns in a lane's window of the local run with lane cursors (a lane runs at most this far ahead of its wave's slowest)
+#ifdef FDCM_LAB
+static constexpr int kLabWin = kCW;
+#else
+static constexpr int kLabWin = 0;
+#endif
+
+// The LDS ring of stack entries, three planes of consecutive dwords: entry i of workgroup lane c is
+// (2 v, P = f + v^2, z) = plane[0..2][i & (kRing - 1)][c].  (Lanes read and write one plane at a time with 4-byte stride: no bank conflicts.)
+struct Ring {
+    float* p;
+    static constexpr int kPlane = kRing * kNT;  // floats per plane
+    __device__ __forceinline__ float4 get(int i, int c) const {
+        const float* a = p + (i & (kRing - 1)) * kNT + c;
+        return make_float4(a[0], a[kPlane], a[2 * kPlane], 0.f);
+    }
+    __device__ __forceinline__ void put(int i, int c, float v2, float P, float z) const {
+        float* a = p + (i & (kRing - 1)) * kNT + c;
+        a[0] = v2; a[kPlane] = P; a[2 * kPlane] = z;
+    }
+    __device__ __forceinline__ void put_z(int i, int c, float z) const { p[2 * kPlane + (i & (kRing - 1)) * kNT + c] = z; }
+};
 
 struct SweepLds {
     unsigned long long smask[64];    // the slice's seeded columns, 64 per word (W <= 4096)
@@ -55,6 +79,9 @@ struct SweepLds {
     int s_slot0[kSeg];               // first HBM slot of a range's entries (its first column: ranges are disjoint)
     int s_lcount[64];                // owner entries per row
     int s_pi[kSeg][64];              // [p - 1][row]: list index that owns the first pixel of fill part p
+#ifdef FDCM_LAB
+    float qwin[kSeg][kCW];           // local run with lane cursors: 2 q of the columns in a wave's window
+#endif
 };
 
 // position of the t-th set bit (t from 0) of the mask words; wave-uniform
@@ -70,16 +97,33 @@ __device__ __forceinline__ int select_column(const unsigned long long* smask, in
 // Stack entries in registers and in the ring are (float(2 v), P = f[v] + v^2, z): the numerator of imgproc.h:111,
 // ((f[q] + q^2) - f[v]) - v^2, is the exact integer P_q - P_v whatever the order (every term is an integer below 2^24), so
 // the test takes one subtraction, and f[v] = P - v^2 comes back exactly where an entry leaves for memory.
-__device__ __forceinline__ EnvEntry to_mem(const float4& e) {
-    const float vf = 0.5f * e.x;
-    return EnvEntry{(int)vf, e.y - vf * vf, e.z};
-}
-__device__ __forceinline__ float4 from_mem(const EnvEntry& e) {
-    const float vf = (float)e.v;
-    return make_float4(vf + vf, e.f + vf * vf, e.z, 0.f);
+__device__ __forceinline__ EnvEntry to_mem(const float4& e) { return EnvEntry{e.x, e.y, e.z}; }
+__device__ __forceinline__ float4 from_mem(const EnvEntry& e) { return make_float4(e.v2, e.P, e.z, 0.f); }
+// ---- end of a local run: the top joins the entries; everything in the ring also goes to HBM (the ring keeps its content
+// for the merge)
+__device__ __forceinline__ void local_finish(const Ring ring, EnvEntry* __restrict__ ent, int tid, float tvx2, float tP, float tz, int& cnt, int& base) {
+    if (cnt - base == kRing) { ent[base] = to_mem(ring.get(base, tid)); ++base; }
+    ring.put(cnt, tid, tvx2, tP, tz);
+    ++cnt;
+#pragma unroll
+    for (int e = 0; e < kRing; ++e) {
+        const int i = base + e;
+        if (i < cnt) ent[i] = to_mem(ring.get(i, tid));
+    }
+    // The merge looks at the 8 entries below a range's top first.  After a run of pops the ring holds fewer than that (it is
+    // only refilled when empty): the missing ones come back from HBM now, all lanes and entries in one trip, instead of one
+    // trip per junction later.
+    const int want = max(cnt - kRing, 0);
+    if (__builtin_amdgcn_ballot_w64(base > want) != 0ull) {
+        const EnvEntry t0 = ent[max(base - 1, 0)], t1 = ent[max(base - 2, 0)], t2 = ent[max(base - 3, 0)], t3 = ent[max(base - 4, 0)],
+                       t4 = ent[max(base - 5, 0)], t5 = ent[max(base - 6, 0)], t6 = ent[max(base - 7, 0)];
+        auto put = [&](const EnvEntry& e, int idx) { if (idx >= want) { const float4 m = from_mem(e); ring.put(idx, tid, m.x, m.y, m.z); } };
+        put(t0, base - 1); put(t1, base - 2); put(t2, base - 3); put(t3, base - 4); put(t4, base - 5); put(t5, base - 6); put(t6, base - 7);
+        base = min(base, want);
+    }
 }
 __device__ __forceinline__ void local_run(const uint4* __restrict__ dp, int W, const unsigned long long* smask, int q0, int ql, int lane,
-                                          int y, int tid, float4 (*ring)[kNT], EnvEntry* __restrict__ ent, int& cnt_out, int& base_out) {
+                                          int y, int tid, const Ring ring, EnvEntry* __restrict__ ent, int& cnt_out, int& base_out) {
     const float inf = f_inf();
     const uint4 db = dp[q0];
     // top entry t and the entry below it u (a register copy of ring entry cnt - 1, so that a single pop needs no LDS round trip)
@@ -94,29 +138,55 @@ __device__ __forceinline__ void local_run(const uint4* __restrict__ dp, int W, c
     int cnt = 0;   // entries below the top (indices 0..cnt-1); [base, cnt) in the LDS ring, [0, base) in HBM
     int base = 0;
     auto evict = [&]() {
-        ent[base] = to_mem(ring[base & (kRing - 1)][tid]);
+        ent[base] = to_mem(ring.get(base, tid));
         ++base;
     };
-    const unsigned lanebase = (unsigned)(size_t)&ring[0][tid];  // LDS byte address of this lane's ring entry 0 (entry i: + i * 8192)
-    static_assert(kNT * sizeof(float4) == 8192, "the pop loop below shifts the ring index by 13");
+    const unsigned lanebase = (unsigned)(size_t)(ring.p + tid);  // LDS byte address of this lane's ring entry 0, plane 0 (entry i: + i * 2048; planes 16384 apart)
+    static_assert(kNT * sizeof(float) == 2048 && Ring::kPlane * sizeof(float) == 16384, "the pop loop below shifts the ring index by 11 and has the plane offsets written out");
     const int qlo = q0 + 1, qhi = ql;
     if (qlo <= qhi) {
-        const int wlo = qlo >> 6, whi = qhi >> 6;
-        for (int wd = wlo; wd <= whi; ++wd) {
-            unsigned long long mk = uni64(smask[wd]);  // columns without a seed in the slice never own a pixel: skipped
-            if (wd == wlo) mk &= ~0ull << (qlo & 63);
-            if (wd == whi) mk &= ~0ull >> (63 - (qhi & 63));
-            while (mk) {
-                const int j = __ffsll((long long)mk) - 1;
-                mk &= mk - 1ull;
-                const int q = wd * 64 + j;
-                // the column's descriptor: the same 16 bytes for every lane, so a scalar load into SGPRs (written out: left to
-                // itself the compiler fetches the seed word with a vector load and waits for every store in flight)
-                u32x4 dq;
-                asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dq) : "s"(dp + q) : "memory");
-                const float fq = column_value_sq_seeded(((unsigned long long)dq.y << 32) | dq.x, (int)dq.z, (int)dq.w, lane, y);
+        // The range's seeded columns in order (columns without a seed in the slice never own a pixel: skipped).  A column's
+        // descriptor is the same 16 bytes for every lane: a scalar load into SGPRs (left to itself the compiler fetches the seed
+        // word with a vector load and waits for every store in flight), issued one column ahead -- it lands behind the waits
+        // of this column's pop loop instead of being waited for on the spot (~250 cycles per column).
+        const int whi = qhi >> 6;
+        int wd = qlo >> 6;
+        unsigned long long mk = uni64(smask[wd]) & (~0ull << (qlo & 63));
+        if (wd == whi) mk &= ~0ull >> (63 - (qhi & 63));
+        auto advance = [&]() {  // to the next word of the range with a seeded column, if any
+            while (mk == 0ull && wd < whi) {
+                ++wd;
+                mk = uni64(smask[wd]);
+                if (wd == whi) mk &= ~0ull >> (63 - (qhi & 63));
+            }
+        };
+        advance();
+        u32x4 dq;
+        int q = -1;
+        if (mk) {
+            q = wd * 64 + __ffsll((long long)mk) - 1;
+            mk &= mk - 1ull;
+            advance();
+            asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dq) : "s"(dp + q) : "memory");
+        } else {
+            dq = u32x4{0u, 0u, 0u, 0u};
+        }
+        while (q >= 0) {
+            {
+                const unsigned long long wc = ((unsigned long long)dq.y << 32) | dq.x;
+                const int pc = (int)dq.z, nc = (int)dq.w;
                 const float qf = (float)q;
-                const float hq = fq + qf * qf;  // P of column q (q * q rounds like the reference's float(long(q * q)))
+                u32x4 dqn = dq;
+                if (mk) {  // the next column's descriptor: in flight until the pop loop's waits
+                    q = wd * 64 + __ffsll((long long)mk) - 1;
+                    mk &= mk - 1ull;
+                    advance();
+                    asm volatile("s_load_dwordx4 %0, %1, 0x0" : "=s"(dqn) : "s"(dp + q) : "memory");
+                } else {
+                    q = -1;
+                }
+                const float fq = column_value_sq_seeded(wc, pc, nc, lane, y);
+                const float hq = fq + qf * qf;  // P of this column (q * q rounds like the reference's float(long(q * q)))
                 const float twoq = qf + qf;
                 float s;
                 // The pop loop, written out and without exec masks.  s = ((f[q] + q^2) - f[v] - v^2) / (2q - 2v) (imgproc.h:111)
@@ -156,10 +226,10 @@ __device__ __forceinline__ void local_run(const uint4* __restrict__ dp, int W, c
                         "v_cmp_eq_u32 %[sx], %[cnt], %[base]\n\t"
                         "v_cmp_lt_i32 %[sy], 0, %[cnt]\n\t"
                         "v_and_b32 %[ua], 7, %[ua]\n\t"
-                        "v_lshl_add_u32 %[ua], %[ua], 13, %[lb]\n\t"
+                        "v_lshl_add_u32 %[ua], %[ua], 11, %[lb]\n\t"
                         "ds_read_b32 %[uv], %[ua]\n\t"
-                        "ds_read_b32 %[up], %[ua] offset:4\n\t"
-                        "ds_read_b32 %[uz], %[ua] offset:8\n\t"
+                        "ds_read_b32 %[up], %[ua] offset:16384\n\t"
+                        "ds_read_b32 %[uz], %[ua] offset:32768\n\t"
                         "s_and_b64 %[sx], %[sx], %[sy]\n\t"
                         "s_and_b64 %[sx], %[sx], vcc\n\t"
                         "s_cbranch_scc0 L_fdcm_pop_%=\n\t"
@@ -177,49 +247,221 @@ __device__ __forceinline__ void local_run(const uint4* __restrict__ dp, int W, c
                             if (cnt == base) {  // ring empty: up to four spilled entries come back together
                                 // all four are written (the ring is empty; entries below 0 land in free slots): no load stays pending
                                 const EnvEntry e0 = ent[max(base - 1, 0)], e1 = ent[max(base - 2, 0)], e2 = ent[max(base - 3, 0)], e3 = ent[max(base - 4, 0)];
-                                ring[(base - 1) & (kRing - 1)][tid] = from_mem(e0);
-                                ring[(base - 2) & (kRing - 1)][tid] = from_mem(e1);
-                                ring[(base - 3) & (kRing - 1)][tid] = from_mem(e2);
-                                ring[(base - 4) & (kRing - 1)][tid] = from_mem(e3);
+                                const float4 m0 = from_mem(e0), m1 = from_mem(e1), m2 = from_mem(e2), m3 = from_mem(e3);
+                                ring.put(base - 1, tid, m0.x, m0.y, m0.z);
+                                ring.put(base - 2, tid, m1.x, m1.y, m1.z);
+                                ring.put(base - 3, tid, m2.x, m2.y, m2.z);
+                                ring.put(base - 4, tid, m3.x, m3.y, m3.z);
                                 base = max(base - 4, 0);
                             }
-                            const float4 e = ring[(cnt - 1) & (kRing - 1)][tid];
+                            const float4 e = ring.get(cnt - 1, tid);
                             uv = e.x; up = e.y; uz = e.z;
                         }
                     }
                 } while (flag);
                 if (__builtin_expect(cnt - base == kRing, 0)) evict();
                 uv = tvx2; up = tP; uz = tz;
-                ring[cnt & (kRing - 1)][tid] = make_float4(tvx2, tP, tz, 0.f);
+                ring.put(cnt, tid, tvx2, tP, tz);
                 ++cnt;
                 tP = hq; tz = s; tvx2 = twoq;
+                asm volatile("; the next column's descriptor has landed (the pop loop ends with s_waitcnt lgkmcnt(0))" : "+s"(dqn));
+                dq = dqn;
             }
         }
     }
-    // the top joins the entries; everything in the ring also goes to HBM (the ring keeps its content for the merge)
-    if (cnt - base == kRing) evict();
-    ring[cnt & (kRing - 1)][tid] = make_float4(tvx2, tP, tz, 0.f);
-    ++cnt;
-#pragma unroll
-    for (int e = 0; e < kRing; ++e) {
-        const int i = base + e;
-        if (i < cnt) ent[i] = to_mem(ring[i & (kRing - 1)][tid]);
-    }
-    // The merge looks at the 8 entries below a range's top first.  After a run of pops the ring holds fewer than that (it is
-    // only refilled when empty): the missing ones come back from HBM now, all lanes and entries in one trip, instead of one
-    // trip per junction later.
-    {
-        const int want = max(cnt - kRing, 0);
-        if (__builtin_amdgcn_ballot_w64(base > want) != 0ull) {
-            const EnvEntry t0 = ent[max(base - 1, 0)], t1 = ent[max(base - 2, 0)], t2 = ent[max(base - 3, 0)], t3 = ent[max(base - 4, 0)],
-                           t4 = ent[max(base - 5, 0)], t5 = ent[max(base - 6, 0)], t6 = ent[max(base - 7, 0)];
-            auto put = [&](const EnvEntry& e, int idx) { if (idx >= want) ring[idx & (kRing - 1)][tid] = from_mem(e); };
-            put(t0, base - 1); put(t1, base - 2); put(t2, base - 3); put(t3, base - 4); put(t4, base - 5); put(t5, base - 6); put(t6, base - 7);
-            base = min(base, want);
-        }
-    }
+    local_finish(ring, ent, tid, tvx2, tP, tz, cnt, base);
     cnt_out = cnt; base_out = base;
 }
+
+#ifdef FDCM_LAB
+// ---- (lab builds only: FDCM_SWEEP_LOCAL=cursors) the same construction with a column cursor per lane.  Measured in round 5
+// and not shipped: the local run is bound by the instructions a wave issues (tools/valu_issue_bench.hip: 2 - 3 cycles of its
+// SIMD per vector instruction with four waves on it, ~5 per instruction for a wave by itself), and a pass with its own
+// cursor takes ~45 instructions where the shared cursor's takes 20: config 2 0.22 ms against 0.195, although the longest wave
+// makes 201 passes instead of 482 (profiles/NOTES.md section 11).  In local_run the wave shares the cursor: a column costs the
+// wave as many passes as its slowest row needs (a heavy wave of BASELINE config 2: 4.8 per column where a row makes 2).
+// Here every lane walks the range's columns by itself, one test per pass: pop the top, or push the column and move on.
+// The wave stages the columns -- every lane's P = f + q^2 into the lane's own LDS window of kCW columns, the columns' 2 q
+// into a table of the wave -- one at a time, as soon as the slowest lane has left the window slot: a lane runs at most kCW
+// columns ahead of the slowest (tools/sim/cursor_sim.cpp: the longest wave of config 2 makes 205 - 232 passes instead of
+// 482).  A pass is one statement of assembly: the entry below the top and the next column are read from LDS at its start and
+// waited for behind the quotient, so nothing is in flight between two passes; its LDS traffic is conflict-free.
+__device__ __forceinline__ void local_run_cursors(const uint4* __restrict__ dp, int W, const unsigned long long* smask, int q0, int ql, int lane, int y, int tid,
+                                                  const Ring ring, float* __restrict__ fwin, float* __restrict__ qwin, EnvEntry* __restrict__ ent,
+                                                  int& cnt_out, int& base_out, long long* lab) {
+#ifdef FDCM_LAB
+    long long n_pass = 0, n_stage = 0, n_flag = 0, cyc_pass = 0, cyc_stage = 0;
+    const long long cyc0 = __builtin_amdgcn_s_memtime();
+#endif
+    const float inf = f_inf();
+    const uint4 db = dp[q0];
+    float tvx2, tP, tz = -inf;  // the top entry
+    {
+        const float vf = (float)q0;
+        tvx2 = vf + vf;
+        tP = column_value_sq_seeded(((unsigned long long)db.y << 32) | db.x, (int)db.z, (int)db.w, lane, y) + vf * vf;
+    }
+    int cnt = 0, base = 0;  // entries below the top: [base, cnt) in the LDS ring, [0, base) in HBM
+    const int qlo = q0 + 1, qhi = ql;
+    if (qlo <= qhi) {
+        float* fw = fwin + tid;  // column j of the range: fw[(j & (kCW - 1)) * kNT]
+        const unsigned lb = (unsigned)(size_t)(ring.p + tid), fwb = (unsigned)(size_t)fw, qwb = (unsigned)(size_t)qwin;
+        // the range's seeded columns, word by word (columns without a seed in the slice never own a pixel: skipped)
+        const int whi = qhi >> 6;
+        int wd = qlo >> 6;
+        unsigned long long mk = uni64(smask[wd]) & (~0ull << (qlo & 63));
+        if (wd == whi) mk &= ~0ull >> (63 - (qhi & 63));
+        while (mk == 0ull && wd < whi) {
+            ++wd;
+            mk = uni64(smask[wd]);
+            if (wd == whi) mk &= ~0ull >> (63 - (qhi & 63));
+        }
+        int staged = 0;              // columns of the range staged so far (wave-uniform)
+        int c = 0;                   // this lane's cursor: it is testing column c of the range (waiting for it when c == staged)
+        float hq = 0.f, twoq = 0.f;  // P and 2 q of column c
+        int flag = 0;                // the last pass left a lane with a full ring, or an empty one above the stack's bottom
+        for (;;) {
+            // ---- stage the next column while the slot is free: no lane may still have to read column staged - kCW from it
+            while (mk != 0ull && __builtin_amdgcn_ballot_w64(c < staged - kCW) == 0ull) {
+#ifdef FDCM_LAB
+                const long long cs0 = __builtin_amdgcn_s_memtime();
+                ++n_stage;
+#endif
+                const int j = __ffsll((long long)mk) - 1;
+                mk &= mk - 1ull;
+                const int q = wd * 64 + j;
+                // the column's descriptor: the same 16 bytes for every lane, so a scalar load into SGPRs (a vector load would
+                // wait for every eviction store in flight: loads and stores share the counter)
+                u32x4 dq;
+                asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dq) : "s"(dp + q) : "memory");
+                const float fq = column_value_sq_seeded(((unsigned long long)dq.y << 32) | dq.x, (int)dq.z, (int)dq.w, lane, y);
+                const float qf = (float)q;
+                const float P = fq + qf * qf;  // q * q rounds like the reference's float(long(q * q))
+                const int slot = staged & (kCW - 1);
+                fw[slot * kNT] = P;
+                if (lane == 0) qwin[slot] = qf + qf;
+                if (c == staged) { hq = P; twoq = qf + qf; }  // lanes that were waiting for this column
+                ++staged;
+                while (mk == 0ull && wd < whi) {
+                    ++wd;
+                    mk = uni64(smask[wd]);
+                    if (wd == whi) mk &= ~0ull >> (63 - (qhi & 63));
+                }
+#ifdef FDCM_LAB
+                cyc_stage += __builtin_amdgcn_s_memtime() - cs0;
+#endif
+            }
+            if (__builtin_amdgcn_ballot_w64(c < staged) == 0ull) break;  // every lane is through (a waiting lane would have had its column staged)
+            // ---- the ring between passes.  A pass may always push (a free slot) and always pop (the entry below the top is in
+            // the ring): when the last pass left some lane with a full ring, or an empty one above spilled entries, every lane
+            // that is close to either state is served with it -- rings with 7 or 8 entries send their oldest to memory until 5 are
+            // left (stores: nothing waits for them), rings with at most one entry above spilled ones get four back (the wave
+            // waits for those once: the lanes of a wave reach such points within a few passes of each other).
+            if (flag) {  // wave-uniform
+#ifdef FDCM_LAB
+                ++n_flag;
+#endif
+                const int d = cnt - base;
+                if (__builtin_amdgcn_ballot_w64(d >= 7) != 0ull) {
+#pragma unroll
+                    for (int e = 0; e < 3; ++e)
+                        if (d - e > 5) ent[base + e] = to_mem(ring.get(base + e, tid));
+                    if (d >= 7) base += d - 5;
+                }
+                const bool rf = d <= 1 && base > 0;
+                if (__builtin_amdgcn_ballot_w64(rf) != 0ull) {
+                    if (rf) {
+                        // all four are written (at most one slot is taken; entries below 0 land in free slots): no load stays pending
+                        const EnvEntry e0 = ent[max(base - 1, 0)], e1 = ent[max(base - 2, 0)], e2 = ent[max(base - 3, 0)], e3 = ent[max(base - 4, 0)];
+                        ring.put(base - 1, tid, e0.v2, e0.P, e0.z);
+                        ring.put(base - 2, tid, e1.v2, e1.P, e1.z);
+                        ring.put(base - 3, tid, e2.v2, e2.P, e2.z);
+                        ring.put(base - 4, tid, e3.v2, e3.P, e3.z);
+                        base = max(base - 4, 0);
+                    }
+                }
+            }
+            // ---- one pass: s = ((f[q] + q^2) - f[v] - v^2) / (2q - 2v) (imgproc.h:111) by envelope_quotient's four instructions;
+            // pop (imgproc.h:113-115) while s <= z[k] (the bottom's z is -inf: never popped), else push (:117-120) and move on.
+            // flag = 1 when a lane's ring is full or empty (above the bottom) afterwards.
+#ifdef FDCM_LAB
+            const long long cp0 = __builtin_amdgcn_s_memtime();
+            ++n_pass;
+#endif
+            {
+                float s, lv, lp, lz, nh, nq, qd, qn, qr, qe;
+                unsigned a, wa;
+                unsigned long long sall, sact, spop, spush, sx;
+                asm volatile(
+                    "s_mov_b64 %[sall], exec\n\t"
+                    "v_cmp_gt_i32 vcc, %[staged], %[c]\n\t"
+                    "v_add_u32 %[a], -1, %[cnt]\n\t"
+                    "s_and_b64 %[sact], vcc, exec\n\t"
+                    "v_and_b32 %[a], 7, %[a]\n\t"
+                    "v_add_u32 %[wa], 1, %[c]\n\t"
+                    "v_lshl_add_u32 %[a], %[a], 11, %[lb]\n\t"
+                    "v_and_b32 %[wa], %[cwm], %[wa]\n\t"
+                    "ds_read_b32 %[lv], %[a]\n\t"
+                    "ds_read_b32 %[lp], %[a] offset:16384\n\t"
+                    "ds_read_b32 %[lz], %[a] offset:32768\n\t"
+                    "v_lshl_add_u32 %[a], %[wa], 11, %[fwb]\n\t"
+                    "v_lshl_add_u32 %[wa], %[wa], 2, %[qwb]\n\t"
+                    "ds_read_b32 %[nh], %[a]\n\t"
+                    "ds_read_b32 %[nq], %[wa]\n\t"
+                    "v_sub_f32 %[qd], %[twoq], %[tv]\n\t"
+                    "v_sub_f32 %[qn], %[hq], %[tp]\n\t"
+                    "v_rcp_f32 %[qr], %[qd]\n\t"
+                    "v_and_b32 %[wa], 7, %[cnt]\n\t"
+                    "v_mul_f32 %[s], %[qn], %[qr]\n\t"
+                    "v_fma_f32 %[qe], -%[qd], %[s], %[qn]\n\t"
+                    "v_fmac_f32 %[s], %[qe], %[qr]\n\t"
+                    "v_lshl_add_u32 %[wa], %[wa], 11, %[lb]\n\t"
+                    "v_cmp_le_f32 vcc, %[s], %[tz]\n\t"
+                    "s_and_b64 %[spop], vcc, %[sact]\n\t"
+                    "s_andn2_b64 %[spush], %[sact], %[spop]\n\t"
+                    "s_waitcnt lgkmcnt(0)\n\t"
+                    "s_mov_b64 exec, %[spush]\n\t"
+                    "ds_write2st64_b32 %[wa], %[tv], %[tp] offset1:64\n\t"
+                    "ds_write_b32 %[wa], %[tz] offset:32768\n\t"
+                    "v_add_u32 %[cnt], 1, %[cnt]\n\t"
+                    "v_add_u32 %[c], 1, %[c]\n\t"
+                    "v_mov_b32 %[tv], %[twoq]\n\t"
+                    "v_mov_b32 %[tp], %[hq]\n\t"
+                    "v_mov_b32 %[tz], %[s]\n\t"
+                    "v_mov_b32 %[hq], %[nh]\n\t"
+                    "v_mov_b32 %[twoq], %[nq]\n\t"
+                    "s_mov_b64 exec, %[spop]\n\t"
+                    "v_add_u32 %[cnt], -1, %[cnt]\n\t"
+                    "v_mov_b32 %[tv], %[lv]\n\t"
+                    "v_mov_b32 %[tp], %[lp]\n\t"
+                    "v_mov_b32 %[tz], %[lz]\n\t"
+                    "s_mov_b64 exec, %[sact]\n\t"
+                    "v_sub_u32 %[a], %[cnt], %[base]\n\t"
+                    "v_cmp_lt_i32 %[sx], 0, %[cnt]\n\t"
+                    "v_and_b32 %[a], 7, %[a]\n\t"
+                    "v_cmp_eq_u32 vcc, 0, %[a]\n\t"
+                    "s_and_b64 %[sx], %[sx], vcc\n\t"
+                    "s_cselect_b32 %[flag], 1, 0\n\t"
+                    "s_mov_b64 exec, %[sall]"
+                    : [s] "=&v"(s), [tv] "+v"(tvx2), [tp] "+v"(tP), [tz] "+v"(tz), [cnt] "+v"(cnt), [c] "+v"(c), [hq] "+v"(hq), [twoq] "+v"(twoq),
+                      [flag] "=&s"(flag), [lv] "=&v"(lv), [lp] "=&v"(lp), [lz] "=&v"(lz), [nh] "=&v"(nh), [nq] "=&v"(nq), [qd] "=&v"(qd), [qn] "=&v"(qn), [qr] "=&v"(qr),
+                      [qe] "=&v"(qe), [a] "=&v"(a), [wa] "=&v"(wa), [sall] "=&s"(sall), [sact] "=&s"(sact), [spop] "=&s"(spop), [spush] "=&s"(spush),
+                      [sx] "=&s"(sx)
+                    : [staged] "s"(staged), [lb] "v"(lb), [fwb] "v"(fwb), [qwb] "s"(qwb), [base] "v"(base), [cwm] "n"(kCW - 1)
+                    : "vcc", "scc", "memory");
+            }
+#ifdef FDCM_LAB
+            cyc_pass += __builtin_amdgcn_s_memtime() - cp0;
+#endif
+        }
+    }
+#ifdef FDCM_LAB
+    if (lab && lane == 0) { lab[16] = n_pass; lab[17] = n_stage; lab[18] = n_flag; lab[19] = cyc_pass; lab[20] = cyc_stage; lab[21] = __builtin_amdgcn_s_memtime() - cyc0; }
+#endif
+    local_finish(ring, ent, tid, tvx2, tP, tz, cnt, base);
+    cnt_out = cnt; base_out = base;
+}
+#endif  // FDCM_LAB
 
 // ---- Phase 2 lane layout: wave j works on the rows 8 j .. 8 j + 7 of the chunk, lane = 8 g + t with g the row inside
 // the wave and t = 0..7.  The 8 lanes of a row hold the row's state in copies and spend their width on 8 stack entries
@@ -237,22 +479,22 @@ __device__ __forceinline__ int first_pixel(float z, float Wf) { return (int)floo
 // behind it against the entry it landed on at once (entry c + 1 pops entry c if its local z -- its quotient on c, the very
 // test the reference makes -- is <= c's quotient on the landing entry; landing deeper only raises that quotient, so what
 // this decides the reference decides too, and what it leaves open the next round settles).
-__device__ __forceinline__ void merge_bulk(SweepLds& L, int S, int row, int t, int sh, float4 (*ring)[kNT], EnvEntry* __restrict__ entr, long long* lab) {
+__device__ __forceinline__ void merge_bulk(SweepLds& L, int S, int row, int t, int sh, const Ring ring, EnvEntry* __restrict__ entr, long long* lab) {
 #ifdef FDCM_LAB
     long long n_iter = 0, n_hbm = 0, n_refill = 0;
 #endif
     // entry idx of (range seg, this row) as (2 v, P = f + v^2, z); from the LDS ring when it is still there, else from HBM
     auto fetch = [&](int seg, int idx, int sbase, int sslot, bool need) -> float4 {
-        float4 e = ring[idx & (kRing - 1)][seg * 64 + row];
+        float4 e = ring.get(idx, seg * 64 + row);
         const bool hb = need && idx < sbase;
         if (__builtin_amdgcn_ballot_w64(hb) != 0ull) {
 #ifdef FDCM_LAB
             ++n_hbm;
 #endif
             const EnvEntry h = entr[sslot + idx];
-            int hv; float hf, hz;
-            asm volatile("v_mov_b32 %0, %3\n\tv_mov_b32 %1, %4\n\tv_mov_b32 %2, %5" : "=&v"(hv), "=&v"(hf), "=&v"(hz) : "v"(h.v), "v"(h.f), "v"(h.z));
-            if (hb) { const float vf = (float)hv; e = make_float4(vf + vf, hf + vf * vf, hz, 0.f); }
+            float hv, hf, hz;
+            asm volatile("v_mov_b32 %0, %3\n\tv_mov_b32 %1, %4\n\tv_mov_b32 %2, %5" : "=&v"(hv), "=&v"(hf), "=&v"(hz) : "v"(h.v2), "v"(h.P), "v"(h.z));
+            if (hb) e = make_float4(hv, hf, hz, 0.f);
         }
         return e;
     };
@@ -266,12 +508,10 @@ __device__ __forceinline__ void merge_bulk(SweepLds& L, int S, int row, int t, i
         if (w < S) {
             const int nw = L.t_cnt[w][row], ws = L.s_slot0[w];
             const EnvEntry ea = entr[ws + min(cb + t, nw - 1)];
-            const float av = (float)ea.v;
-            c.a2v = av + av; c.ahq = ea.f + av * av; c.az = ea.z;
+            c.a2v = ea.v2; c.ahq = ea.P; c.az = ea.z;
             if (both) {
                 const EnvEntry eb = entr[ws + min(cb + t + 8, nw - 1)];
-                const float bv = (float)eb.v;
-                c.b2v = bv + bv; c.bhq = eb.f + bv * bv; c.bz = eb.z;
+                c.b2v = eb.v2; c.bhq = eb.P; c.bz = eb.z;
             }
         }
         return c;
@@ -375,7 +615,7 @@ __device__ __forceinline__ void merge_bulk(SweepLds& L, int S, int row, int t, i
         L.t_hi[ms][row] = mi;
         L.t_prev[w][row] = ms;
         L.t_lo[w][row] = cur;
-        if (cur >= wbase) ring[cur & (kRing - 1)][w * 64 + row].z = zc;
+        if (cur >= wbase) ring.put_z(cur, w * 64 + row, zc);
         entr[wslot + cur].z = zc;
         ms = w; mi = nw - 1; ms_lo = cur; ms_base = wbase; ms_slot = wslot;
     }
@@ -415,14 +655,19 @@ __device__ __forceinline__ void walk_batched(SweepLds& L, int W, int S, int part
         for (int j = 1; j < kSeg; ++j) w += i >= o[j] ? 1 : 0;  // the last range that starts at or before i (empty ranges in between start there too)
         return i + L.t_K[w][row];
     };
-    auto load = [&](int i) -> EnvEntry { return ent[slot_of(min(i, total - 1))]; };
+    struct WalkEntry { int v; float f; float z; };  // column, f[v], z (the entries in memory hold 2 v and f[v] + v^2)
+    auto load = [&](int i) -> WalkEntry {
+        const EnvEntry m = ent[slot_of(min(i, total - 1))];
+        const float vf = 0.5f * m.v2;
+        return WalkEntry{(int)vf, m.P - vf * vf, m.z};
+    };
     const float Wf = (float)W;
     int lc = 0;    // owner entries of the row so far
     int optr = 0;  // list index of the owner of the column looked up last (columns only grow, so do the owners)
     const int tmax = __builtin_amdgcn_readfirstlane(wave_max(total));
-    EnvEntry en = load(t), nx = load(8 + t);
+    WalkEntry en = load(t), nx = load(8 + t);
     for (int i0 = 0; i0 < tmax; i0 += 8) {
-        const EnvEntry e = en;
+        const WalkEntry e = en;
         en = nx;
         nx = load(i0 + 16 + t);  // in flight during the next step
         const int i = i0 + t;
@@ -573,19 +818,26 @@ __device__ __forceinline__ void fill_part(SweepLds& L, float* __restrict__ vol, 
 __global__ void __launch_bounds__(kNT) k_sweep_balanced(const ColDesc* __restrict__ desc, float* __restrict__ vol, int W, int H, int HW64, int part_w,
                                                         SweepBuf B) {
     // one LDS pool for the phases: the construction's rings (kept through the merge), the walk's lists, the fill's staging
-    constexpr size_t kPoolBytes = std::max({(size_t)kRing * kNT * sizeof(float4), (size_t)3 * 64 * kWinStride * 4, (size_t)3 * kRE * kNT * 4});
+    constexpr size_t kPoolBytes = std::max({(size_t)(3 * kRing + kLabWin) * kNT * sizeof(float), (size_t)3 * 64 * kWinStride * 4, (size_t)3 * kRE * kNT * 4});
     __shared__ SweepLds L;
     __shared__ float4 pool[kPoolBytes / sizeof(float4)];
     const long long t_start = wall_clock64();
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const long chunk = B.order ? B.order[blockIdx.x] : (long)blockIdx.x;
 #ifdef FDCM_LAB
-    long long* lab = B.lab ? B.lab + ((size_t)chunk * kSeg + wave) * 16 : nullptr;
+    long long* lab = B.lab ? B.lab + ((size_t)chunk * kSeg + wave) * kLabN : nullptr;
 #define LAB_STAMP(i) do { if (lab && lane == 0) lab[i] = wall_clock64(); } while (0)
 #else
 #define LAB_STAMP(i) do { } while (0)
 #endif
     LAB_STAMP(0);
+#ifdef FDCM_LAB
+    if (lab && lane == 0) {  // where the workgroup runs: HW_ID (CU, SH, SE) and the XCC
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw), "=s"(xcc));
+        lab[22] = hw; lab[23] = xcc;
+    }
+#endif
     const long k = chunk / HW64;
     const int c = (int)(chunk - k * HW64);
     const int y = c * 64 + lane;
@@ -613,12 +865,19 @@ __global__ void __launch_bounds__(kNT) k_sweep_balanced(const ColDesc* __restric
         if (tid == 0) B.cost[chunk] = (int)(wall_clock64() - t_start);
         return;
     }
-    const int S = min(kSeg, max(1, n / kMinCols));  // ranges of this slice
-    float4(*ring)[kNT] = reinterpret_cast<float4(*)[kNT]>(pool);
+    const int S = min(kSeg, max(1, n / max(1, B.min_cols)));  // ranges of this slice (min_cols: kMinCols unless FDCM_SWEEP_MINCOLS says otherwise)
+    const Ring ring{reinterpret_cast<float*>(pool)};
+#ifdef FDCM_LAB
+    float* fwin = reinterpret_cast<float*>(pool) + 3 * Ring::kPlane;  // [kCW][kNT]: the windows of column values of the local run with lane cursors
+#endif
     if (wave < S) {
         const int j0 = (int)(((long)n * wave) / S), j1 = (int)(((long)n * (wave + 1)) / S);  // ranks of the range's columns: [j0, j1), never empty
         const int q0 = select_column(L.smask, j0), ql = select_column(L.smask, j1 - 1);
         int cnt, base;
+#ifdef FDCM_LAB
+        if (B.lane_cursors) local_run_cursors(dp, W, L.smask, q0, ql, lane, y, tid, ring, fwin, L.qwin[wave], B.ent + r * (size_t)B.eslots + q0, cnt, base, lab);
+        else
+#endif
         local_run(dp, W, L.smask, q0, ql, lane, y, tid, ring, B.ent + r * (size_t)B.eslots + q0, cnt, base);
         L.t_cnt[wave][lane] = cnt; L.t_base[wave][lane] = base;
         if (lane == 0) L.s_slot0[wave] = q0;
@@ -692,9 +951,14 @@ void launch_sweep_balanced(hipStream_t st, const void* desc, float* vol, int W, 
     SweepBuf B = B_;
     B.min_cols = env_min_cols;
 #ifdef FDCM_LAB
+    // FDCM_SWEEP_LOCAL=cursors (lab builds): the local run with a column cursor per lane, for comparisons
+    static const int env_cursors = [] { const char* e = getenv("FDCM_SWEEP_LOCAL"); return (e && std::strcmp(e, "cursors") == 0) ? 1 : 0; }();
+    B.lane_cursors = env_cursors;
+#endif
+#ifdef FDCM_LAB
     if (getenv("FDCM_SWEEP_LAB")) {  // per-wave phase times (100 MHz clock) and counters of this launch, on stderr
         static DevBuf labbuf;
-        const size_t nl = (size_t)nchunks * kSeg * 16;
+        const size_t nl = (size_t)nchunks * kSeg * kLabN;
         labbuf.reserve(nl * 8);
         FDCM_HIP(hipMemsetAsync(labbuf.p, 0, nl * 8, st));
         SweepBuf B2 = B;
@@ -707,14 +971,14 @@ void launch_sweep_balanced(hipStream_t st, const void* desc, float* vol, int W, 
         std::vector<long long> d(nl);
         FDCM_HIP(hipMemcpy(d.data(), labbuf.p, nl * 8, hipMemcpyDeviceToHost));
         long long t0 = 0x7fffffffffffffffll, t1 = 0;
-        for (long ch = 0; ch < nchunks; ++ch) for (int w = 0; w < kSeg; ++w) { const long long* e = &d[((size_t)ch * kSeg + w) * 16]; if (e[0]) { t0 = std::min(t0, e[0]); t1 = std::max(t1, e[7]); } }
+        for (long ch = 0; ch < nchunks; ++ch) for (int w = 0; w < kSeg; ++w) { const long long* e = &d[((size_t)ch * kSeg + w) * kLabN]; if (e[0]) { t0 = std::min(t0, e[0]); t1 = std::max(t1, e[7]); } }
         auto pct = [](std::vector<double>& v, double q) { if (v.empty()) return 0.0; std::sort(v.begin(), v.end()); return v[(size_t)(q * (v.size() - 1))]; };
         const char* names[7] = {"local run", "wait 1", "merge", "wait 2", "owner walk", "wait 3", "fill"};
         fprintf(stderr, "[sweep lab] %ld chunks, kernel span %.1f us (first stamp to last)\n", nchunks, (t1 - t0) / 100.0);
         for (int ph = 0; ph < 7; ++ph) {
             std::vector<double> v;
             for (long ch = 0; ch < nchunks; ++ch) for (int w = 0; w < kSeg; ++w) {
-                const long long* e = &d[((size_t)ch * kSeg + w) * 16];
+                const long long* e = &d[((size_t)ch * kSeg + w) * kLabN];
                 if (!e[0]) continue;
                 v.push_back((e[ph + 1] - e[ph]) / 100.0);
             }
@@ -724,13 +988,13 @@ void launch_sweep_balanced(hipStream_t st, const void* desc, float* vol, int W, 
         {
             std::vector<double> life, start, cols, it, hb, lst;
             for (long ch = 0; ch < nchunks; ++ch) {
-                const long long* e = &d[(size_t)ch * kSeg * 16];
+                const long long* e = &d[(size_t)ch * kSeg * kLabN];
                 if (!e[0]) continue;
                 long long end = 0;
-                for (int w = 0; w < kSeg; ++w) end = std::max(end, d[((size_t)ch * kSeg + w) * 16 + 7]);
+                for (int w = 0; w < kSeg; ++w) end = std::max(end, d[((size_t)ch * kSeg + w) * kLabN + 7]);
                 life.push_back((end - e[0]) / 100.0); start.push_back((e[0] - t0) / 100.0);
                 it.push_back((double)e[12]); hb.push_back((double)e[13]);
-                for (int w = 0; w < kSeg; ++w) { cols.push_back((double)d[((size_t)ch * kSeg + w) * 16 + 9]); lst.push_back((double)d[((size_t)ch * kSeg + w) * 16 + 10]); }
+                for (int w = 0; w < kSeg; ++w) { cols.push_back((double)d[((size_t)ch * kSeg + w) * kLabN + 9]); lst.push_back((double)d[((size_t)ch * kSeg + w) * kLabN + 10]); }
             }
             double ls = 0; for (double x : life) ls += x;
             fprintf(stderr, "[sweep lab] block life us: mean %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f (sum %.0f); block start us: p50 %.1f p90 %.1f max %.1f\n", ls / life.size(), pct(life, .5), pct(life, .9),
@@ -739,8 +1003,8 @@ void launch_sweep_balanced(hipStream_t st, const void* desc, float* vol, int W, 
                 std::vector<std::pair<double, long>> ends;
                 for (long ch = 0; ch < nchunks; ++ch) {
                     long long end = 0;
-                    for (int w = 0; w < kSeg; ++w) end = std::max(end, d[((size_t)ch * kSeg + w) * 16 + 7]);
-                    if (d[(size_t)ch * kSeg * 16]) ends.push_back({(end - t0) / 100.0, ch});
+                    for (int w = 0; w < kSeg; ++w) end = std::max(end, d[((size_t)ch * kSeg + w) * kLabN + 7]);
+                    if (d[(size_t)ch * kSeg * kLabN]) ends.push_back({(end - t0) / 100.0, ch});
                 }
                 std::sort(ends.begin(), ends.end());
                 for (size_t i = ends.size() > 6 ? ends.size() - 6 : 0; i < ends.size(); ++i) {
@@ -748,7 +1012,7 @@ void launch_sweep_balanced(hipStream_t st, const void* desc, float* vol, int W, 
                     double ph[7] = {0, 0, 0, 0, 0, 0, 0}, st0 = 1e30;
                     long long cols = 0, depth = 0, iters = 0, hbm = 0, refill = 0, owners = 0;
                     for (int w = 0; w < kSeg; ++w) {
-                        const long long* e = &d[((size_t)ch * kSeg + w) * 16];
+                        const long long* e = &d[((size_t)ch * kSeg + w) * kLabN];
                         st0 = std::min(st0, (e[0] - t0) / 100.0);
                         for (int q = 0; q < 7; ++q) ph[q] = std::max(ph[q], (e[q + 1] - e[q]) / 100.0);
                         cols = std::max(cols, e[9]); depth = std::max(depth, e[10]); iters = std::max(iters, e[12]); hbm = std::max(hbm, e[13]); refill = std::max(refill, e[14]);
@@ -760,8 +1024,45 @@ void launch_sweep_balanced(hipStream_t st, const void* desc, float* vol, int W, 
             }
             {
                 std::vector<double> a, b, c;
-                for (long ch = 0; ch < nchunks; ++ch) for (int w = 0; w < kSeg; ++w) { const long long v = d[((size_t)ch * kSeg + w) * 16 + 15]; if (!d[((size_t)ch * kSeg + w) * 16]) continue; a.push_back((double)(v >> 40) / 100.0); b.push_back((double)((v >> 20) & 0xfffff) / 100.0); c.push_back((double)(v & 0xfffff) / 100.0); }
+                for (long ch = 0; ch < nchunks; ++ch) for (int w = 0; w < kSeg; ++w) { const long long v = d[((size_t)ch * kSeg + w) * kLabN + 15]; if (!d[((size_t)ch * kSeg + w) * kLabN]) continue; a.push_back((double)(v >> 40) / 100.0); b.push_back((double)((v >> 20) & 0xfffff) / 100.0); c.push_back((double)(v & 0xfffff) / 100.0); }
                 fprintf(stderr, "[sweep lab] merge: incoming entries arrive after p50 %.1f p90 %.1f us; junction loops p50 %.1f p90 %.1f us; first step of the first junction p50 %.2f p90 %.2f us\n", pct(a, .5), pct(a, .9), pct(b, .5), pct(b, .9), pct(c, .5), pct(c, .9));
+            }
+            {
+                std::vector<double> np, ns, nf, cp, cs, ct;
+                double snp = 0, scp = 0, sns = 0, scs = 0, sct = 0;
+                long long hp = 0, hcp = 0, hs = 0, hcs = 0, hct = 0, hf = 0;
+                for (long ch = 0; ch < nchunks; ++ch) for (int w = 0; w < kSeg; ++w) {
+                    const long long* e = &d[((size_t)ch * kSeg + w) * kLabN];
+                    if (!e[0] || !e[16]) continue;
+                    np.push_back((double)e[16]); ns.push_back((double)e[17]); nf.push_back((double)e[18]);
+                    cp.push_back((double)e[19] / (double)e[16]); cs.push_back(e[17] ? (double)e[20] / (double)e[17] : 0.0); ct.push_back((double)e[21]);
+                    snp += (double)e[16]; scp += (double)e[19]; sns += (double)e[17]; scs += (double)e[20]; sct += (double)e[21];
+                    if (e[21] > hct) { hct = e[21]; hp = e[16]; hcp = e[19]; hs = e[17]; hcs = e[20]; hf = e[18]; }
+                }
+                if (!np.empty())
+                    fprintf(stderr, "[sweep lab] lane cursors: passes per wave p50 %.0f p90 %.0f max %.0f; stagings p50 %.0f max %.0f; slow passes p50 %.0f max %.0f; s_memtime ticks per pass: mean %.0f p50 %.0f p90 %.0f; per staging: mean %.0f; share of the local run: passes %.0f %%, stagings %.0f %%; longest wave: %lld ticks = %lld passes (%lld ticks) + %lld stagings (%lld ticks), %lld slow\n",
+                            pct(np, .5), pct(np, .9), pct(np, 1.0), pct(ns, .5), pct(ns, 1.0), pct(nf, .5), pct(nf, 1.0), scp / snp, pct(cp, .5), pct(cp, .9), scs / std::max(1.0, sns), 100.0 * scp / sct, 100.0 * scs / sct, hct, hp, hcp, hs, hcs, hf);
+            }
+            if (atoi(getenv("FDCM_SWEEP_LAB")) == 2) {  // which workgroups share a CU
+                std::vector<std::pair<unsigned long long, long>> where;
+                for (long ch = 0; ch < nchunks; ++ch) {
+                    const long long* e = &d[(size_t)ch * kSeg * kLabN];
+                    if (!e[0]) continue;
+                    const unsigned hw = (unsigned)e[22], xcc = (unsigned)e[23] & 0xf;
+                    const unsigned cu = (hw >> 8) & 0xf, shid = (hw >> 12) & 1, se = (hw >> 13) & 7;
+                    where.push_back({((unsigned long long)xcc << 24) | (se << 16) | (shid << 8) | cu, ch});
+                }
+                std::sort(where.begin(), where.end());
+                fprintf(stderr, "[sweep lab] placement (xcc.se.sh.cu: chunks in launch position order):");
+                unsigned long long last = ~0ull;
+                int shown = 0;
+                for (auto& w : where) {
+                    if (w.first != last) { if (++shown > 40) break; fprintf(stderr, "\n[sweep lab]   %llu.%llu.%llu.%llu:", w.first >> 24, (w.first >> 16) & 0xff, (w.first >> 8) & 0xff, w.first & 0xff); last = w.first; }
+                    long long end = 0;
+                    for (int w2 = 0; w2 < kSeg; ++w2) end = std::max(end, d[((size_t)w.second * kSeg + w2) * kLabN + 7]);
+                    fprintf(stderr, " %ld(%.0f-%.0f)", w.second, (d[(size_t)w.second * kSeg * kLabN] - t0) / 100.0, (end - t0) / 100.0);
+                }
+                fprintf(stderr, "\n");
             }
             fprintf(stderr, "[sweep lab] columns per wave p50 %.0f max %.0f; deepest local stack p50 %.0f p99 %.0f max %.0f; merge iterations per block p50 %.0f p90 %.0f max %.0f, with an HBM fetch p50 %.0f p90 %.0f max %.0f\n",
                     pct(cols, .5), pct(cols, 1.0), pct(lst, .5), pct(lst, .99), pct(lst, 1.0), pct(it, .5), pct(it, .9), pct(it, 1.0), pct(hb, .5), pct(hb, .9), pct(hb, 1.0));
