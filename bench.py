@@ -95,7 +95,7 @@ def pmc_search_traffic(config):
     return None, None, "k_search is not in the summary"
 
 
-def cpu_baseline(cfg, scene, tmpls, sample_templates, reps):
+def cpu_baseline(cfg, scene, tmpls, sample_templates, reps, warmup=True):
     """Oracle on the host cores: one build + search over the first `sample_templates` templates (by default all of
     them: nothing is scaled), median of `reps`.  The oracle's workers are a long-lived pool, as the reference's
     BS::thread_pool is, so thread start-up is not what is timed.  Returns (json object, the oracle's match records)."""
@@ -103,7 +103,8 @@ def cpu_baseline(cfg, scene, tmpls, sample_templates, reps):
     cores = os.cpu_count() or 1
     sub = tmpls[:sample_templates]
     builds, searches = [], []
-    fm = O.build(scene, depth=cfg["depth"], coeff=5.0, padding=1.0, distance=cfg["distance"], nthreads=cores)  # warm-up
+    if warmup:
+        fm = O.build(scene, depth=cfg["depth"], coeff=5.0, padding=1.0, distance=cfg["distance"], nthreads=cores)
     for _ in range(reps):
         t0 = time.perf_counter()
         fm = O.build(scene, depth=cfg["depth"], coeff=5.0, padding=1.0, distance=cfg["distance"], nthreads=cores)
@@ -118,8 +119,8 @@ def cpu_baseline(cfg, scene, tmpls, sample_templates, reps):
         "value": len(m) * scale / frame, "unit": "matches/s", "cores": cores, "kind": "port",
         "sample": f"1 DT3 build ({t_build * 1e3:.0f} ms) + search of " + (f"all {len(tmpls)} templates ({t_search * 1e3:.0f} ms)" if scale == 1
                   else f"the first {len(sub)} of {len(tmpls)} templates ({t_search * 1e3:.0f} ms, scaled x{scale:g})") +
-                  f" with {cores} threads (a long-lived pool), 1 warm-up + median of {reps} runs "
-                  f"(~{(t_build + t_search) * cores * (reps + 1):.0f} core-seconds in all); the oracle is a restatement "
+                  f" with {cores} threads (a long-lived pool), {1 if warmup else 0} warm-up + median of {reps} run(s) "
+                  f"(~{(t_build + t_search) * cores * (reps + (1 if warmup else 0)):.0f} core-seconds in all); the oracle is a restatement "
                   "(the reference cannot be built here) that omits the reference's two O(V) deep copies",
         "dt3_build_ms": t_build * 1e3, "search_matches_per_s": len(m) / t_search,
     }, m
@@ -160,6 +161,7 @@ def main():
                          "than one, EVERY collected frame of the timed region is checked against the oracle's records of its "
                          "own scene after the run (a frame/slot mix-up in the pipeline or the gather would show)")
     ap.add_argument("--cpu-reps", type=int, default=5, help="CPU baseline runs (median)")
+    ap.add_argument("--cpu-warmup", type=int, default=1, help="0: no warm-up build of the CPU baseline (the large configs: a build takes a minute)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         relaunch_under_torchrun(args)
@@ -324,10 +326,13 @@ def main():
                                  "slowest": (lambda i: {"frame": int(i), "latency": frame_log[i][0], "build_span": frame_log[i][1],
                                                         "search_span": frame_log[i][2], "search_kernels": frame_log[i][3]})(int(np.argmax(lat)))},
             "templates_per_s": total_templates * K / elapsed,
-            "dt3_build_ms": avg["total_ms"], "search_ms": acc["search_total_ms"] / K,
+            # BASELINE.json's "DT3 build ms": the build's kernels with the GPU to itself (set below from the blocking frames;
+            # the span of a build inside the timed region, where F frames share the CUs, is in_timed_region.dt3_build_span_ms)
+            "dt3_build_ms": None,
             "in_timed_region": {"note": f"per-launch HIP-event times with {F} frames in flight: launches of concurrent "
                                         "frames share the CUs, so these exceed ms_per_step and the blocking figures",
                                 "stage_ms": {k: round(v, 4) for k, v in avg.items()}, "build_kernels_ms": kernels_ms,
+                                "dt3_build_span_ms": avg["total_ms"], "search_span_ms": acc["search_total_ms"] / K,
                                 "search_kernel_ms": acc["search_kernel_ms"] / K},
         }
         if single:
@@ -368,14 +373,18 @@ def main():
                 "b_ms": b_ms, "s_ms": s_ms_,
                 "strong_speedup_bound": {str(n): (b_ms + s_ms_) / (b_ms + s_ms_ / n) for n in (1, 2, 4, 8)},
                 "weak_speedup_bound": {str(n): float(n) for n in (1, 2, 4, 8)}}
+            out["dt3_build_ms"] = span
+            out["search_kernels_ms"] = single["search_kernel_ms"]
             out["single_frame_ms"] = single["frame_ms"]
             out["single_frame_matches_per_s"] = n_matches / (single["frame_ms"] * 1e-3)
+        if out["dt3_build_ms"] is None:  # --single-frames 0: only the contended span is known
+            out["dt3_build_ms"] = avg["total_ms"]
         if args.cpu_sample != 0:
             # Rank 0 at every N: the oracle runs the WHOLE job's template list (all shards), so at N > 1 the gate compares the
             # GATHERED list -- every rank's records after the RCCL exchange, in the reference's positional order
             # (defaultmatch.cpp:76-86) -- and the baseline is timed on the same job the N GPUs ran.
             sample = total_templates if args.cpu_sample < 0 else min(args.cpu_sample, total_templates)
-            out["cpu_baseline"], want0 = cpu_baseline(cfg, scene, all_templates[:total_templates], sample, args.cpu_reps)
+            out["cpu_baseline"], want0 = cpu_baseline(cfg, scene, all_templates[:total_templates], sample, args.cpu_reps, bool(args.cpu_warmup))
 
             def same_as_oracle(got_all, want):
                 got = got_all[got_all["tmpl_idx"] < sample]

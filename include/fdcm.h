@@ -289,6 +289,10 @@ int64_t fdcm_selftest_atanf(uint32_t first, uint32_t stride, uint64_t count);
  * glibc -- or FDCM_FORCE_HOST_BINS=1; slower: every search recomputes align / transform / atanf of every candidate
  * line on the host, and says so once on stderr).  Decided at the first call of this function or of a search. */
 int fdcm_orientation_bins_mode(void);
+/* Column ranges the balanced L2 / L2^2 sweep cuts a row of a slice with n seeded columns into (1 .. 8; csrc/fdcm_sweep.h:
+ * the kernel calls the same function).  FDCM_SWEEP_MINCOLS=1..64, the tests' switch, lowers the columns a range holds at
+ * least from 16, so that small test images exercise all 8 ranges: this call lets a test see that the switch took. */
+int fdcm_selftest_sweep_ranges(int n_seeded_columns);
 
 #ifdef __cplusplus
 }

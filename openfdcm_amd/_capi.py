@@ -102,6 +102,7 @@ SYMBOLS = [
     ("fdcm_lines_free", None, [C.POINTER(C.c_float)]),
     ("fdcm_selftest_atanf", C.c_int64, [C.c_uint32, C.c_uint32, C.c_uint64]),
     ("fdcm_orientation_bins_mode", C.c_int, []),
+    ("fdcm_selftest_sweep_ranges", C.c_int, [C.c_int]),
 ]
 
 _lib = None

@@ -9,6 +9,7 @@
 #include <thread>
 
 #include "fdcm_internal.h"
+#include "fdcm_sweep.h"
 
 namespace fdcm {
 int device_cus(int device) {
@@ -62,12 +63,14 @@ static void destroy(fdcm_featuremap* fm) {
     if (!fm) return;
     (void)hipSetDevice(fm->device);
     if (fm->stream) (void)hipStreamSynchronize(fm->stream);
+    if (fm->prep_stream) (void)hipStreamSynchronize(fm->prep_stream);
     fm->vol.release(); fm->ivol.release(); fm->bitmap.release(); fm->coldesc.release(); fm->colmask.release(); fm->offtab.release(); fm->stack.release(); fm->plan.release(); fm->stage.release();
     fm->s_scene.release(); fm->s_pairs.release(); fm->s_records.release(); fm->s_flags.release(); fm->s_out.release(); fm->s_work.release(); fm->s_tail.release(); fm->s_tail_out.release(); fm->s_eval.release();
     fm->s_counter.release(); fm->s_stage.release(); fm->s_cnt.release(); fm->s_bins.release(); fm->s_bins_stage.release();
     if (fm->timing.created)
         for (auto& e : fm->timing.ev) (void)hipEventDestroy(e);
     if (fm->stream) (void)hipStreamDestroy(fm->stream);
+    if (fm->prep_stream) { (void)hipStreamDestroy(fm->prep_stream); (void)hipEventDestroy(fm->prep_done); }
     delete fm;
 }
 }  // namespace fdcm
@@ -561,5 +564,6 @@ int64_t fdcm_selftest_atanf(uint32_t first, uint32_t stride, uint64_t count) {
 }
 
 int fdcm_orientation_bins_mode(void) { return fdcm::orientation_bins_on_host() ? 1 : 0; }
+int fdcm_selftest_sweep_ranges(int n_seeded_columns) { return fdcm::sweep_ranges(n_seeded_columns, fdcm::sweep_min_cols()); }
 
 }  // extern "C"

@@ -108,6 +108,8 @@ struct Timing {
 struct fdcm_featuremap {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t prep_stream = nullptr;  // the search's preparation beside a running build (handles that have the GPU to themselves)
+    hipEvent_t prep_done = nullptr;
     // parameters
     int64_t depth_param = 0;
     float coeff = 0, padding = 0;

@@ -553,6 +553,71 @@ __global__ void __launch_bounds__(1024) k_scatter(const fdcm_match* __restrict__
     }
 }
 
+// The same compaction in one launch, for searches of at most kCompactChunks chunks (65 536 candidates): a block sums the
+// flags of the chunks before its own itself (at most 256 KB from L2) instead of reading per-chunk counts that an earlier
+// launch left -- one kernel boundary and one small kernel less on a blocking frame.
+static constexpr int kCompactChunks = 64;
+__global__ void __launch_bounds__(1024) k_compact(const fdcm_match* __restrict__ records, const int* __restrict__ flags,
+                                                  const int* __restrict__ evals, long long n, int nchunks,
+                                                  fdcm_match* __restrict__ out, unsigned long long* __restrict__ counters,
+                                                  fdcm_match* __restrict__ out2, unsigned long long* __restrict__ counters2) {
+    __shared__ long long wsum[16];
+    __shared__ long long chunk_base;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long i = (long long)blockIdx.x * kChunk + tid;
+    const int f = i < n ? flags[i] : 0;
+    fdcm_match r{};
+    if (f) r = records[i];  // in flight while the earlier chunks are summed
+    long long s = 0;
+    {
+        const int4* f4 = reinterpret_cast<const int4*>(flags);  // whole chunks: multiples of 1024 ints from an aligned base
+        const long long n4 = (long long)blockIdx.x * (kChunk / 4);
+        for (long long q = tid; q < n4; q += 1024) { const int4 v = f4[q]; s += v.x + v.y + v.z + v.w; }
+    }
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
+    if (lane == 0) wsum[wave] = s;
+    __syncthreads();
+    if (tid == 0) {
+        long long b = 0;
+        for (int w = 0; w < 16; ++w) b += wsum[w];
+        chunk_base = b;
+    }
+    int incl = f;
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(incl, d);
+        if (lane >= d) incl += o;
+    }
+    __syncthreads();
+    const long long cb = chunk_base;
+    __syncthreads();
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    long long wbase = 0;
+    for (int w = 0; w < wave; ++w) wbase += wsum[w];
+    if (f) {
+        out[cb + wbase + incl - 1] = r;
+        if (out2) out2[cb + wbase + incl - 1] = r;  // pinned host memory: the caller's copy, written in place
+    }
+    if ((int)blockIdx.x == nchunks - 1) {
+        if (tid == 1023) {
+            counters[2] = (unsigned long long)(cb + wbase + incl);
+            if (counters2) counters2[2] = (unsigned long long)(cb + wbase + incl);
+        }
+        long long ev = 0;
+        for (long long i2 = tid; i2 < n; i2 += 1024) ev += evals[i2];
+        for (int d = 32; d >= 1; d >>= 1) ev += __shfl_xor(ev, d);
+        __syncthreads();
+        if (lane == 0) wsum[wave] = ev;
+        __syncthreads();
+        if (tid == 0) {
+            long long tot = 0;
+            for (int w = 0; w < 16; ++w) tot += wsum[w];
+            counters[0] = (unsigned long long)tot;
+            if (counters2) counters2[0] = (unsigned long long)tot;
+        }
+    }
+}
+
 int64_t search_capacity(const fdcm_templates* t, int64_t n_scene, int64_t maxT, int64_t maxS) {
     int64_t total = 0;
     // the reference takes size_t limits and applies min(tmpl.cols(), maxTmplLines) / min(scene, maxSceneLines)
@@ -640,7 +705,19 @@ void run_search(fdcm_featuremap* fm, const fdcm_templates* t, const float* scene
     int* hi = (int*)(hs + o_idx);
     for (int i = 0; i < n_s; ++i) { hl[i] = slen[sidx[i]]; hi[i] = (int)sidx[i]; }
     std::memcpy(hs + o_coff, coff.data(), coff.size() * 8);
-    FDCM_HIP(hipMemcpyAsync(fm->s_scene.p, hs, blob, hipMemcpyHostToDevice, st));
+    // The search's preparation (scene upload, k_pairs, the work list) needs nothing of the volume: on a handle that has the GPU
+    // to itself it goes to a second stream, beside the kernels of a build that is still running on `st` (a blocking
+    // rebuild -> search spends ~25 us less); k_search waits for it through an event.  A slot of a frame pipeline keeps one
+    // stream (its frames already run beside each other, and every stream takes a hardware queue).
+    hipStream_t sp = st;
+    if (!fm->shares_gpu) {
+        if (!fm->prep_stream) {
+            FDCM_HIP(hipStreamCreateWithFlags(&fm->prep_stream, hipStreamNonBlocking));
+            FDCM_HIP(hipEventCreateWithFlags(&fm->prep_done, hipEventDisableTiming));
+        }
+        sp = fm->prep_stream;
+    }
+    FDCM_HIP(hipMemcpyAsync(fm->s_scene.p, hs, blob, hipMemcpyHostToDevice, sp));
     const int nchunks = (int)((ncand + kChunk - 1) / kChunk);
     fm->s_records.reserve((size_t)ncand * sizeof(fdcm_match));
     fm->s_flags.reserve(2 * ((size_t)ncand + (size_t)nchunks) * sizeof(int));
@@ -693,28 +770,32 @@ void run_search(fdcm_featuremap* fm, const fdcm_templates* t, const float* scene
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t* ev = fm->timing.ev;
     FDCM_HIP(hipEventRecord(ev[6], st));
-    hipLaunchKernelGGL(k_pairs, dim3((unsigned)(((size_t)t->T * maxT + 255) / 256)), dim3(256), 0, st, P);
+    hipLaunchKernelGGL(k_pairs, dim3((unsigned)(((size_t)t->T * maxT + 255) / 256)), dim3(256), 0, sp, P);
     const long long n_slots = (long long)t->T * P.pairs_stride;
     static const bool no_worklist = getenv("FDCM_SEARCH_TEMPLATE_MAJOR") != nullptr;  // tuning override
     if (!no_worklist && n_slots <= 0x7fffffffll) {
         const size_t work_bytes = ((size_t)(ncand / 2) * sizeof(int2) + 15) & ~(size_t)15;
         fm->s_work.reserve(work_bytes + 2 * (size_t)kWorkBins * sizeof(int));
         if (n_slots <= kWlSlotsPerBlock) {
-            hipLaunchKernelGGL(k_worklist, dim3(1), dim3(1024), 0, st, P, n_slots, fm->s_work.as<int2>());
+            hipLaunchKernelGGL(k_worklist, dim3(1), dim3(1024), 0, sp, P, n_slots, fm->s_work.as<int2>());
         } else {
             int* ghist = (int*)((char*)fm->s_work.p + work_bytes);
             int* cursor = ghist + kWorkBins;
             const unsigned nb = (unsigned)((n_slots + kWlSlotsPerBlock - 1) / kWlSlotsPerBlock);
-            FDCM_HIP(hipMemsetAsync(ghist, 0, (size_t)kWorkBins * sizeof(int), st));
-            hipLaunchKernelGGL(k_wl_count, dim3(nb), dim3(1024), 0, st, P, n_slots, ghist);
-            hipLaunchKernelGGL(k_wl_starts, dim3(1), dim3(1024), 0, st, ghist, cursor);
-            hipLaunchKernelGGL(k_wl_scatter, dim3(nb), dim3(1024), 0, st, P, n_slots, ghist, cursor, fm->s_work.as<int2>());
+            FDCM_HIP(hipMemsetAsync(ghist, 0, (size_t)kWorkBins * sizeof(int), sp));
+            hipLaunchKernelGGL(k_wl_count, dim3(nb), dim3(1024), 0, sp, P, n_slots, ghist);
+            hipLaunchKernelGGL(k_wl_starts, dim3(1), dim3(1024), 0, sp, ghist, cursor);
+            hipLaunchKernelGGL(k_wl_scatter, dim3(nb), dim3(1024), 0, sp, P, n_slots, ghist, cursor, fm->s_work.as<int2>());
         }
         P.work = fm->s_work.as<int2>();
         P.nblocks = (int)(((ncand + kWavesPerBlock - 1) / kWavesPerBlock + 7) / 8 * 8);
     } else {
         P.work = nullptr;
         P.nblocks = (int)((size_t)t->T * P.bpt);
+    }
+    if (sp != st) {  // k_search (and the host bins' upload) behind the preparation
+        FDCM_HIP(hipEventRecord(fm->prep_done, sp));
+        FDCM_HIP(hipStreamWaitEvent(st, fm->prep_done, 0));
     }
     if (host_bins_needed) {
         if (fm->m > 65535) throw std::string("host-side orientation bins need depth <= 65535");
@@ -818,9 +899,15 @@ void run_search(fdcm_featuremap* fm, const fdcm_templates* t, const float* scene
         fm->s_cnt.reserve(64);
         FDCM_HIP(hipHostGetDevicePointer((void**)&host_cnt, fm->s_cnt.p, 0));
     }
-    hipLaunchKernelGGL(k_chunk_counts, dim3((unsigned)nchunks), dim3(256), 0, st, P.flags, P.evals, ncand, d_counts, d_evsums);
-    hipLaunchKernelGGL(k_scatter, dim3((unsigned)nchunks), dim3(1024), 0, st, P.records, P.flags, ncand, d_counts, d_evsums,
-                       nchunks, dst, P.counters, host_out, host_cnt);
+    static const bool env_two_step = getenv("FDCM_SEARCH_COMPACT2") != nullptr;  // the tests' switch: the two-kernel form at every size
+    if (nchunks <= kCompactChunks && !env_two_step) {
+        hipLaunchKernelGGL(k_compact, dim3((unsigned)nchunks), dim3(1024), 0, st, P.records, P.flags, P.evals, ncand, nchunks, dst, P.counters,
+                           host_out, host_cnt);
+    } else {
+        hipLaunchKernelGGL(k_chunk_counts, dim3((unsigned)nchunks), dim3(256), 0, st, P.flags, P.evals, ncand, d_counts, d_evsums);
+        hipLaunchKernelGGL(k_scatter, dim3((unsigned)nchunks), dim3(1024), 0, st, P.records, P.flags, ncand, d_counts, d_evsums,
+                           nchunks, dst, P.counters, host_out, host_cnt);
+    }
     FDCM_HIP(hipEventRecord(ev[7], st));
     FDCM_HIP(hipGetLastError());
     unsigned long long hc[3] = {0, 0, 0};

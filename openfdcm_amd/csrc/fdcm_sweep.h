@@ -24,6 +24,15 @@ struct SweepBuf {
 #endif
 };
 
+// column ranges per row of a slice with n seeded columns: at most kSweepSegments, each with min_cols columns at least
+// (the kernel and fdcm_debug_sweep_ranges use this one function)
+__host__ __device__ inline int sweep_ranges(int n, int min_cols) {
+    const int s = n / (min_cols > 1 ? min_cols : 1);
+    return s < 1 ? 1 : (s > kSweepSegments ? kSweepSegments : s);
+}
+// seeded columns a range holds at least: 16, or FDCM_SWEEP_MINCOLS = 1..64 (the tests' switch: small images then take all 8 ranges too)
+int sweep_min_cols();
+
 // the sweep applies when every value of the pass is an exact integer (see fdcm_sweep.hip)
 inline bool sweep_balanced_applies(long W, long H) { return W * W + H * H <= (1L << 24); }
 

@@ -865,7 +865,7 @@ __global__ void __launch_bounds__(kNT) k_sweep_balanced(const ColDesc* __restric
         if (tid == 0) B.cost[chunk] = (int)(wall_clock64() - t_start);
         return;
     }
-    const int S = min(kSeg, max(1, n / max(1, B.min_cols)));  // ranges of this slice (min_cols: kMinCols unless FDCM_SWEEP_MINCOLS says otherwise)
+    const int S = sweep_ranges(n, B.min_cols);  // ranges of this slice
     const Ring ring{reinterpret_cast<float*>(pool)};
 #ifdef FDCM_LAB
     float* fwin = reinterpret_cast<float*>(pool) + 3 * Ring::kPlane;  // [kCW][kNT]: the windows of column values of the local run with lane cursors
@@ -942,14 +942,17 @@ __global__ void __launch_bounds__(1024) k_order(const int* __restrict__ cost, in
     for (int i = tid; i < n; i += 1024) order[atomicAdd(&cursor[255 - min(255, max(0, (int)((float)cost[i] * scale)))], 1)] = i;
 }
 
+int sweep_min_cols() {
+    static const int v = [] { const char* e = getenv("FDCM_SWEEP_MINCOLS"); const int x = e ? atoi(e) : 0; return (x >= 1 && x <= 64) ? x : kMinCols; }();
+    return v;
+}
+
 void launch_sweep_order(hipStream_t st, const int* cost, int n, int* order) { hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, st, cost, n, order); }
 
 void launch_sweep_balanced(hipStream_t st, const void* desc, float* vol, int W, int H, int HW64, long nchunks, const SweepBuf& B_) {
     const int part_w = (((W + kSeg - 1) / kSeg) + 3) & ~3;  // fill parts start on a group of 4 columns
-    // FDCM_SWEEP_MINCOLS=1..64 is the tests' switch: small images then take all 8 ranges too (their slices have few columns)
-    static const int env_min_cols = [] { const char* e = getenv("FDCM_SWEEP_MINCOLS"); const int v = e ? atoi(e) : 0; return (v >= 1 && v <= 64) ? v : kMinCols; }();
     SweepBuf B = B_;
-    B.min_cols = env_min_cols;
+    B.min_cols = sweep_min_cols();
 #ifdef FDCM_LAB
     // FDCM_SWEEP_LOCAL=cursors (lab builds): the local run with a column cursor per lane, for comparisons
     static const int env_cursors = [] { const char* e = getenv("FDCM_SWEEP_LOCAL"); return (e && std::strcmp(e, "cursors") == 0) ? 1 : 0; }();

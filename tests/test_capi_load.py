@@ -73,6 +73,21 @@ def test_argument_errors_are_reported_not_thrown(capi):
     assert lib.fdcm_get_device(None) == -1
 
 
+def test_sweep_mincols_switch_takes(capi):
+    """FDCM_SWEEP_MINCOLS reaches the kernel's range count (csrc/fdcm_sweep.h: sweep_ranges is the one function the
+    kernel and this self test call).  Default: 16 columns per range at least; the fuzz variants' 2 and 1 give a slice of 16
+    seeded columns all 8 ranges."""
+    import subprocess
+    import sys
+    assert capi.lib().fdcm_selftest_sweep_ranges(16) == 1 and capi.lib().fdcm_selftest_sweep_ranges(127) == 7
+    assert capi.lib().fdcm_selftest_sweep_ranges(829) == 8 and capi.lib().fdcm_selftest_sweep_ranges(0) == 1
+    code = ("import sys; sys.path.insert(0, %r); from openfdcm_amd import _capi; "
+            "print(_capi.lib().fdcm_selftest_sweep_ranges(16), _capi.lib().fdcm_selftest_sweep_ranges(5))" % ROOT)
+    for val, want in (("2", "8 2"), ("1", "8 5"), ("64", "1 1")):
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env={**os.environ, "FDCM_SWEEP_MINCOLS": val})
+        assert out.returncode == 0 and out.stdout.split("\n")[0].strip() == want, (val, out.stdout, out.stderr[-500:])
+
+
 def test_lineio_roundtrip_and_assets(tmp_path):
     from openfdcm_amd import lineio
     from helpers import create_lines
@@ -125,6 +140,20 @@ def test_lines_read_write_through_the_c_abi(capi, tmp_path):
     rc, msg = c_read(str(junk))
     assert rc == -1 and "not an OPENFDCM line file" in msg
     assert lib.fdcm_lines_read(None, None, None) == -1
+    # a well-formed file with another record length is "unsupported", not "truncated" (the reference does not check
+    # lineDataRecordLen, serialization.h:114-131, but only reads 16-byte lines correctly)
+    import zlib
+    blob = bytearray(open(str(tmp_path / "c_7.lines"), "rb").read())  # outer header: flag @22, sizes @23 / @31, payload @39
+    body = bytearray(zlib.decompress(bytes(blob[39:])) if blob[22] else blob[39:])
+    body[35:37] = (24).to_bytes(2, "little")                          # lineDataRecordLen
+    comp = zlib.compress(bytes(body)) if blob[22] else bytes(body)
+    head = bytearray(blob[:39])
+    head[23:31] = len(body).to_bytes(8, "little")
+    head[31:39] = len(comp).to_bytes(8, "little")
+    odd = tmp_path / "odd.lines"
+    odd.write_bytes(bytes(head) + comp)
+    rc, msg = c_read(str(odd))
+    assert rc == -1 and "unsupported line record length <24>" in msg, msg
 
 
 def _build_c_example(tmp_path):

@@ -532,9 +532,11 @@ def test_search_many_templates_generic_work_list(amd):
                                             ({"FDCM_FORCE_HOST_BINS": "1"}, 40, 15),
                                             ({"FDCM_INT_XC": "256"}, 30, 16),
                                             ({"FDCM_INT_XC": "128"}, 30, 17),
-                                            ({"FDCM_SEARCH_FLAT": "1"}, 30, 18)],
+                                            ({"FDCM_SEARCH_FLAT": "1"}, 30, 18),
+                                            ({"FDCM_SEARCH_COMPACT2": "1"}, 30, 19)],
                          ids=["default", "8-ranges-on-small-slices", "1-column-ranges+launch-order", "literal-one-wave-per-chunk", "host-libm-bins",
-                              "integral-252-chain-blocks", "integral-124-chain-blocks", "search-with-64-bit-addresses"])
+                              "integral-252-chain-blocks", "integral-124-chain-blocks", "search-with-64-bit-addresses",
+                              "two-kernel-compaction"])
 def test_randomised_cases(amd, env, cases, seed):
     """Random (scene, depth, distance, padding, coefficient, optimiser, template set) cases: volume and match list
     bit for bit (tools/fuzz_parity.py).  The variants force the paths of the L2 sweep that the default sizes do not
@@ -542,7 +544,8 @@ def test_randomised_cases(amd, env, cases, seed):
     pop whole ranges, rows whose stack is one entry), the launch order from a cost table, and the literal
     one-wave-per-chunk kernel that sizes above the exact-integer bound take; the orientation bins of the aligned template lines from the host
     libm (the path a host whose atanf differs from the device restatement takes); the wide-block forms of the steep
-    line integral that only large volumes select; the search with 64-bit flat addresses (what volumes of 4 GB and more take)."""
+    line integral that only large volumes select; the search with 64-bit flat addresses (what volumes of 4 GB and more take);
+    the two-kernel form of the positional compaction (what searches of more than 65 536 candidates take)."""
     import os
     import subprocess
     import sys
@@ -693,6 +696,15 @@ def test_sharded_engine_leaves_the_callers_device_alone(amd):
     eng.search(scene, 3, 3)
     assert current() == before
     eng.search_topk(scene, 3, 3, 5, penalty=0)
+    assert current() == before
+    # the asynchronous entry points too (submit sizes the slot's buffers on the shard's device on the caller's thread)
+    t = eng.submit(scene, 3, 3)
+    assert current() == before
+    eng.wait(t)
+    assert current() == before
+    t = eng.submit(scene, 3, 3, k=4, penalty=0)
+    assert current() == before
+    eng.wait(t)
     assert current() == before
     eng.close()
     assert current() == before
