@@ -364,7 +364,10 @@ __global__ void __launch_bounds__(256) k_propagate_reg(const float* __restrict__
 // Lane rho <-> chain a + sg*(rho - 3), sg = sign(r): lanes 0..2 are the halo (the chains that reach the wave's
 // first rows during a group), lanes 3..60 the 58 chains whose rows the wave stores, lanes 61..63 would fall off
 // the 64-row window after 3 moves and are not used.
-static constexpr int kShP = 12;                 // groups (loads of 1 KB) in flight per wave
+#ifndef FDCM_SHP
+#define FDCM_SHP 12
+#endif
+static constexpr int kShP = FDCM_SHP;                 // groups (loads of 1 KB) in flight per wave
 static constexpr int kShOwn = 58, kShHalo = 3;
 // Table per slice, one word per group in sweep order: 16 * (chain offset round(i r) at the group's first step) |
 // bit j: the chains move between the group's steps j and j+1.  Steps outside the image (the padding columns of

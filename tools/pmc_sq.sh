@@ -18,7 +18,7 @@ pass sq2 SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_
 pass sq3 SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT
 pass tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
 pass tcp TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum
-python3 - $OUT <<'PY'
+FDCM_REPO=$R python3 - $OUT <<'PY'
 import csv, sys, os, collections, json
 out = sys.argv[1]
 res = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -28,7 +28,11 @@ for f in sorted(os.listdir(out)):
         k = r['Kernel_Name'].split('(')[0]
         res[k][r['Counter_Name']].append(float(r['Counter_Value']))
 summ = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in res.items()}
-json.dump(summ, open(os.path.join(out, 'summary.json'), 'w'), indent=1)
+import hashlib
+so = os.path.join(os.environ.get('FDCM_REPO', '.'), 'openfdcm_amd', 'libfdcm_hip.so')
+doc = {"source": "rocprofv3 --kernel-trace --pmc <set> (one pass per set) -- python3 bench.py --frames 1 --steps 5 --warmup 2 --cpu-sample 0 --single-frames 0; averages per launch",
+       "so_sha256_16": hashlib.sha256(open(so, 'rb').read()).hexdigest()[:16] if os.path.exists(so) else None, "kernels": summ}
+json.dump(doc, open(os.path.join(out, 'summary.json'), 'w'), indent=1)
 for k, d in summ.items():
     if d.get('SQ_WAVE_CYCLES', 0) < 1e5: continue
     print(k, {c: round(v) for c, v in d.items()})
