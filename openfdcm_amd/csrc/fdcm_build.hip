@@ -619,16 +619,18 @@ static void ensure_timing(fdcm_featuremap* fm) {
     fm->timing.created = true;
 }
 
-void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after) {
+void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after, bool reserve_only) {
     const auto t0 = std::chrono::steady_clock::now();
     FDCM_HIP(hipSetDevice(fm->device));
     if (!fm->stream) FDCM_HIP(hipStreamCreateWithFlags(&fm->stream, hipStreamNonBlocking));
     ensure_timing(fm);
     finish_build(fm);  // the previous build's staging and events are reused below
     hipStream_t st = fm->stream;
-    fm->W = plan.W; fm->H = plan.H; fm->m = plan.m; fm->tx = plan.tx; fm->ty = plan.ty;
-    fm->keys = plan.keys;
-    fm->last_build = fdcm_build_timing{};
+    if (!reserve_only) {  // (a reservation leaves the handle's geometry and content as they are)
+        fm->W = plan.W; fm->H = plan.H; fm->m = plan.m; fm->tx = plan.tx; fm->ty = plan.ty;
+        fm->keys = plan.keys;
+        fm->last_build = fdcm_build_timing{};
+    }
     if (plan.m == 0 || plan.W == 0) return;
     const int W = (int)plan.W, H = (int)plan.H, m = (int)plan.m;
     if (plan.W > 16384 || plan.H > 16384) throw std::string("feature size above 16384 is not supported");  // 32-bit byte offsets inside a slice
@@ -653,6 +655,7 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after) {
     fm->colmask.reserve((size_t)m * ((W + 63) / 64) * 8);
     SweepBuf sb{};
     bool proxy_order = false;
+    std::vector<int32_t> proxy_cost;
     int* order_dst = nullptr;
     if (fm->distance == FDCM_L1) {
         fm->stack.reserve((size_t)m * HW64 * ((W + 63) / 64) * 64 * sizeof(float2));  // the L1 pass's minima / carries
@@ -677,8 +680,9 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after) {
         static const bool env_order = getenv("FDCM_SWEEP_ORDER") != nullptr;  // the tests' switch: the launch order at every size
         const bool want_order = env_order || nchunks > 2L * device_cus(fm->device);
         const bool have_cost = want_order && fm->k2_cost_chunks == nchunks && fm->k2_cost_w == W && stack_before == fm->stack.p;
-        proxy_order = want_order && !have_cost && plan.chunk_cost.size() == (size_t)nchunks;
-        if (have_cost) launch_sweep_order(st, (const int*)(sp + o_cost), (int)nchunks, (int*)(sp + o_ord));
+        proxy_order = want_order && !have_cost && !reserve_only;
+        if (proxy_order) sweep_cost_proxy(plan, proxy_cost);
+        if (have_cost && !reserve_only) launch_sweep_order(st, (const int*)(sp + o_cost), (int)nchunks, (int*)(sp + o_ord));
         order_dst = (int*)(sp + o_ord);
         sb.ent = (EnvEntry*)(sp + o_ent); sb.own = (OwnEntry*)(sp + o_own);
         sb.order = (have_cost || proxy_order) ? (const int*)(sp + o_ord) : nullptr;
@@ -695,15 +699,19 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after) {
     fm->off_integral = fm->off_prop + align16(plan.prop.size() * sizeof(PropStep));
     fm->off_keys = fm->off_integral + align16(plan.integral.size() * sizeof(IntegralDesc));
     fm->off_cost = fm->off_keys + align16(plan.keys.size() * sizeof(float));
-    const size_t blob = fm->off_cost + (proxy_order ? align16(plan.chunk_cost.size() * sizeof(int32_t)) : 0);
+    const size_t blob = fm->off_cost + ((proxy_order || reserve_only) ? align16((size_t)nchunks * sizeof(int32_t)) : 0);
     fm->stage.reserve(blob);
     fm->plan.reserve(blob);
+    if (reserve_only) {  // every buffer a build of this plan's shape takes is in place; nothing was queued
+        fm->k2_cost_chunks = 0;  // (the sweep's cost table of this shape holds nothing yet)
+        return;
+    }
     char* hs = (char*)fm->stage.p;
     if (!plan.raster.empty()) std::memcpy(hs + fm->off_raster, plan.raster.data(), plan.raster.size() * sizeof(RasterLine));
     std::memcpy(hs + fm->off_prop, plan.prop.data(), plan.prop.size() * sizeof(PropStep));
     std::memcpy(hs + fm->off_integral, plan.integral.data(), plan.integral.size() * sizeof(IntegralDesc));
     std::memcpy(hs + fm->off_keys, plan.keys.data(), plan.keys.size() * sizeof(float));
-    if (proxy_order) std::memcpy(hs + fm->off_cost, plan.chunk_cost.data(), plan.chunk_cost.size() * sizeof(int32_t));
+    if (proxy_order) std::memcpy(hs + fm->off_cost, proxy_cost.data(), proxy_cost.size() * sizeof(int32_t));
     FDCM_HIP(hipMemcpyAsync(fm->plan.p, hs, blob, hipMemcpyHostToDevice, st));
     if (proxy_order) launch_sweep_order(st, (const int*)((const char*)fm->plan.p + fm->off_cost), (int)nchunks, order_dst);
     fm->n_raster = (int64_t)plan.raster.size();

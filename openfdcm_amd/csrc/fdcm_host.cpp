@@ -120,6 +120,24 @@ static RasterLine raster_descriptor(const float* l, int slice) {
     return r;
 }
 
+// Proxy of the L2 sweep's time per (slice, 64-row chunk), for the launch order of a build without history (only such a
+// build asks for it: run_build): a row's chain is as long as the slice has seeded columns, and the columns whose seeds lie
+// outside the chunk's 64 rows (rows far from the line: long runs without an envelope vertex) count double
+// (tools/k2_cost_model.py: r = 0.85).
+void sweep_cost_proxy(const BuildPlan& plan, std::vector<int32_t>& cost) {
+    const int HW64 = (int)((plan.H + 63) / 64);
+    cost.assign((size_t)plan.m * HW64, 0);
+    for (const LineBox& b : plan.boxes) {
+        const int ncols = (int)(b.xhi - b.xlo) + 1;
+        for (int c = 0; c < HW64; ++c) {
+            const float c0 = (float)(c * 64), c1 = (float)(c * 64 + 63);
+            const float ov = std::min(b.yhi, c1) - std::max(b.ylo, c0) + 1.f;  // rows of the line's y range inside the chunk
+            const int inside = ov <= 0.f ? 0 : std::min(ncols, (int)(ncols * ov / (b.yhi - b.ylo + 1.f)) + 1);
+            cost[(size_t)b.slice * HW64 + c] += 2 * ncols - inside;
+        }
+    }
+}
+
 void make_build_plan(const float* lines, int64_t n, int64_t depth, float coeff, float padding, BuildPlan& plan) {
     plan = BuildPlan{};
     if (n == 0) return;
@@ -153,21 +171,7 @@ void make_build_plan(const float* lines, int64_t n, int64_t depth, float coeff, 
         const int k = closest_orientation(plan.keys.data(), m, angle);
         if (!clip_line(l, xmax, ymax)) continue;
         per_slice[k].push_back(raster_descriptor(l, k));
-        // Proxy of the sweep's time per (slice, chunk), for the launch order of a build without history: a row's chain
-        // is as long as the slice has seeded columns, and the columns whose seeds lie outside the chunk's 64 rows (rows
-        // far from the line: long runs without an envelope vertex) count double (tools/k2_cost_model.py: r = 0.85).
-        {
-            const int HW64 = (int)((plan.H + 63) / 64);
-            if (plan.chunk_cost.empty()) plan.chunk_cost.assign((size_t)m * HW64, 0);
-            const float xlo = std::min(l[0], l[2]), xhi = std::max(l[0], l[2]), ylo = std::min(l[1], l[3]), yhi = std::max(l[1], l[3]);
-            const int ncols = (int)(xhi - xlo) + 1;
-            for (int c = 0; c < HW64; ++c) {
-                const float c0 = (float)(c * 64), c1 = (float)(c * 64 + 63);
-                const float ov = std::min(yhi, c1) - std::max(ylo, c0) + 1.f;  // rows of the line's y range inside the chunk
-                const int inside = ov <= 0.f ? 0 : std::min(ncols, (int)(ncols * ov / (yhi - ylo + 1.f)) + 1);
-                plan.chunk_cost[(size_t)k * HW64 + c] += 2 * ncols - inside;
-            }
-        }
+        plan.boxes.push_back(LineBox{k, std::min(l[0], l[2]), std::max(l[0], l[2]), std::min(l[1], l[3]), std::max(l[1], l[3])});
     }
     for (auto& v : per_slice) plan.raster.insert(plan.raster.end(), v.begin(), v.end());
     // propagateOrientation step table, dt3cpu.cpp:86-106

@@ -62,6 +62,8 @@ struct IntegralDesc {
     int32_t pad;
 };
 
+struct LineBox { int32_t slice; float xlo, xhi, ylo, yhi; };
+
 struct BuildPlan {
     int64_t W = 0, H = 0, m = 0;
     float tx = 0, ty = 0;
@@ -69,11 +71,13 @@ struct BuildPlan {
     std::vector<RasterLine> raster;
     std::vector<PropStep> prop;
     std::vector<IntegralDesc> integral;
-    std::vector<int32_t> chunk_cost;  // per (slice, 64-row chunk): a proxy of the L2 sweep's time, for the launch order of a first build
+    std::vector<LineBox> boxes;       // the clipped lines' bounding boxes (what sweep_cost_proxy works from)
 };
 
 // Host side of buildCpuFeaturemap (dt3cpu.h:174-198 + the scalar parts of :227-231).
 void make_build_plan(const float* lines, int64_t n, int64_t depth, float coeff, float padding, BuildPlan& plan);
+// per (slice, 64-row chunk): a proxy of the L2 sweep's time, for the launch order of a build without history
+void sweep_cost_proxy(const BuildPlan& plan, std::vector<int32_t>& cost);
 
 FDCM_HD float lin_spaced_value(int mode, float low, float high, float step, int n, int i) {
     // Eigen 3.4.0 linspaced_op_impl<float>::operator() (NullaryFunctors.h), scalar path.
@@ -180,7 +184,8 @@ struct fdcm_templates {
 
 namespace fdcm {
 // implemented in fdcm_build.hip
-void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after);
+// reserve_only: size every buffer a build of this plan takes and queue nothing (the handle keeps its geometry and content)
+void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after, bool reserve_only = false);
 // Waits for a queued build (if any) and fills fm->last_build.  run_build only queues the kernels: the search
 // that follows is ordered behind them on the same stream and its host-side preparation runs meanwhile.
 void finish_build(fdcm_featuremap* fm);
@@ -189,6 +194,8 @@ int64_t search_capacity(const fdcm_templates* t, int64_t n_scene, int64_t maxT, 
 void run_search(fdcm_featuremap* fm, const fdcm_templates* t, const float* scene, int64_t n_scene, int64_t maxT,
                 int64_t maxS, int optimizer, int64_t batch, int32_t base, fdcm_match* out_device, fdcm_match** out_host,
                 int64_t* n_out);
+// sizes the search's workspaces for this template set and scene size, queues nothing (run_search reserves the same sizes)
+void reserve_search(fdcm_featuremap* fm, const fdcm_templates* t, int64_t n_scene, int64_t maxT, int64_t maxS);
 // the searches of this process take the candidates' orientation bins from the host libm (decided once: see fdcm.h)
 bool orientation_bins_on_host();
 // implemented in fdcm_seam.hip: minmaxTranslation<Dt3Cpu> / evaluate<Dt3Cpu> batched over templates

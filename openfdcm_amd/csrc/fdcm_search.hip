@@ -644,6 +644,34 @@ bool orientation_bins_on_host() {
     return on_host;
 }
 
+// The workspaces run_search takes, sized for (template set, scene size, window): the same expressions, nothing queued.
+void reserve_search(fdcm_featuremap* fm, const fdcm_templates* t, int64_t n_scene, int64_t maxT, int64_t maxS) {
+    if (!t || t->T == 0 || n_scene <= 0) return;
+    FDCM_HIP(hipSetDevice(fm->device));
+    maxT = std::min<int64_t>(std::max<int64_t>(maxT, 0), std::max<int64_t>(t->max_lines, 0));
+    maxS = std::min<int64_t>(std::max<int64_t>(maxS, 0), n_scene);
+    const int64_t ncand = search_capacity(t, n_scene, maxT, maxS);
+    if (ncand == 0) return;
+    auto align16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    const size_t n_s = (size_t)n_scene;
+    const size_t blob = align16(n_s * 16) + 2 * align16(n_s * 4) + align16(((size_t)t->T + 1) * 8);
+    const int nchunks = (int)((ncand + kChunk - 1) / kChunk);
+    fm->s_stage.reserve(blob);
+    fm->s_scene.reserve(blob);
+    fm->s_records.reserve((size_t)ncand * sizeof(fdcm_match));
+    fm->s_flags.reserve(2 * ((size_t)ncand + (size_t)nchunks) * sizeof(int));
+    fm->s_counter.reserve(64);
+    fm->s_cnt.reserve(64);
+    const size_t pairs_stride = (size_t)(maxT * maxS);
+    fm->s_pairs.reserve(std::max<size_t>(16, (size_t)t->T * pairs_stride * sizeof(int2)));
+    fm->s_work.reserve((((size_t)(ncand / 2) * sizeof(int2) + 15) & ~(size_t)15) + 2 * (size_t)kWorkBins * sizeof(int));
+    if (orientation_bins_on_host()) {
+        const size_t stride = (size_t)std::max<int64_t>(1, t->max_lines);
+        fm->s_bins_stage.reserve((size_t)ncand * stride * sizeof(unsigned short));
+        fm->s_bins.reserve((size_t)ncand * stride * sizeof(unsigned short));
+    }
+}
+
 void run_search(fdcm_featuremap* fm, const fdcm_templates* t, const float* scene, int64_t n_scene, int64_t maxT,
                 int64_t maxS, int optimizer, int64_t batch, int32_t base, fdcm_match* out_device, fdcm_match** out_host,
                 int64_t* n_out) {

@@ -279,8 +279,9 @@ int64_t submit_frame(fdcm_sharded* s, Job&& job) {
     // Device memory of the slot is sized HERE, on the caller's thread, before its workers get the frame: an allocation is a
     // device-wide synchronisation, and the caller's thread is also the one that runs the exchange of earlier frames (in
     // wait) -- so an allocation can never race a grouped send/recv in flight.  The record buffers take the frame's search
-    // capacity; a slot without a feature map yet (its first frame) builds it once here, so that the worker's rebuild
-    // finds every buffer of the build in place (a later frame with a larger feature size still grows them in the worker).
+    // capacity; the slot's feature map gets every buffer its build and its search will ask for (reservations only: nothing
+    // is built or queued here, and a scene that cannot be built still fails where it always did -- in the frame, reported
+    // by its wait).  A later frame with a larger feature size or more scene lines grows them here the same way.
     for (auto& sh : s->shards) {
         FrameSlot& fs = *sh.slots[si];
         int64_t cap = 0;
@@ -289,8 +290,15 @@ int64_t submit_frame(fdcm_sharded* s, Job&& job) {
         (void)fdcm_set_device(sh.device);
         fs.block.reserve(std::max<size_t>(32, (size_t)cap * sizeof(fdcm_match)));
         if (job.topk) fs.best.reserve(std::max<size_t>(32, (size_t)std::min<int64_t>(std::max<int64_t>(job.k, 0), cap) * sizeof(fdcm_match)));
-        if (!fs.fm && fdcm_featuremap_build(job.scene.data(), job.n_scene, s->depth, s->coeff, s->padding, s->distance, &fs.fm) != FDCM_OK)
-            throw std::string(fdcm_last_error());
+        if (!fs.fm && fdcm_featuremap_build(job.scene.data(), 0, s->depth, s->coeff, s->padding, s->distance, &fs.fm) != FDCM_OK)
+            throw std::string(fdcm_last_error());  // (an empty handle: no lines, no volume)
+        try {
+            BuildPlan plan;
+            make_build_plan(job.scene.data(), s->depth > 0 ? job.n_scene : 0, s->depth, s->coeff, s->padding, plan);
+            run_build(fs.fm, plan, 3, /*reserve_only=*/true);
+            reserve_search(fs.fm, sh.tset, job.n_scene, job.maxT, job.maxS);
+        } catch (const std::string&) {  // e.g. a feature size the build rejects: the frame reports it
+        }
     }
     for (auto& sh : s->shards) {
         FrameSlot& fs = *sh.slots[si];
