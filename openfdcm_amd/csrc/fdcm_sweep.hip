@@ -123,7 +123,11 @@ __device__ __forceinline__ void local_finish(const Ring ring, EnvEntry* __restri
     }
 }
 __device__ __forceinline__ void local_run(const uint4* __restrict__ dp, int W, const unsigned long long* smask, int q0, int ql, int lane,
-                                          int y, int tid, const Ring ring, EnvEntry* __restrict__ ent, int& cnt_out, int& base_out) {
+                                          int y, int tid, const Ring ring, EnvEntry* __restrict__ ent, int& cnt_out, int& base_out, long long* lab) {
+#ifdef FDCM_LAB
+    long long lab_cols = 0, lab_pop = 0, lab_evict = 0;
+    const long long lab_t0 = __builtin_amdgcn_s_memtime();
+#endif
     const float inf = f_inf();
     const uint4 db = dp[q0];
     // top entry t and the entry below it u (a register copy of ring entry cnt - 1, so that a single pop needs no LDS round trip)
@@ -199,6 +203,10 @@ __device__ __forceinline__ void local_run(const uint4* __restrict__ dp, int W, c
                 // The loop leaves with flag = 1 when a popping lane's ring ran empty above the stack's bottom (0 < cnt == base after
                 // the pop): those lanes have pend = 1, took their pop, and get their refill and u below.
                 int flag;
+#ifdef FDCM_LAB
+                ++lab_cols;
+                const long long lab_p0 = __builtin_amdgcn_s_memtime();
+#endif
                 do {
                     int pend, c1;
                     unsigned long long sx, sy;
@@ -259,6 +267,10 @@ __device__ __forceinline__ void local_run(const uint4* __restrict__ dp, int W, c
                         }
                     }
                 } while (flag);
+#ifdef FDCM_LAB
+                lab_pop += __builtin_amdgcn_s_memtime() - lab_p0;
+                if (__builtin_amdgcn_ballot_w64(cnt - base == kRing) != 0ull) ++lab_evict;
+#endif
                 if (__builtin_expect(cnt - base == kRing, 0)) evict();
                 uv = tvx2; up = tP; uz = tz;
                 ring.put(cnt, tid, tvx2, tP, tz);
@@ -269,6 +281,9 @@ __device__ __forceinline__ void local_run(const uint4* __restrict__ dp, int W, c
             }
         }
     }
+#ifdef FDCM_LAB
+    if (lab && lane == 0) { lab[16] = 0; lab[17] = lab_cols; lab[18] = lab_evict; lab[19] = lab_pop; lab[20] = 0; lab[21] = __builtin_amdgcn_s_memtime() - lab_t0; }
+#endif
     local_finish(ring, ent, tid, tvx2, tP, tz, cnt, base);
     cnt_out = cnt; base_out = base;
 }
@@ -878,7 +893,11 @@ __global__ void __launch_bounds__(kNT) k_sweep_balanced(const ColDesc* __restric
         if (B.lane_cursors) local_run_cursors(dp, W, L.smask, q0, ql, lane, y, tid, ring, fwin, L.qwin[wave], B.ent + r * (size_t)B.eslots + q0, cnt, base, lab);
         else
 #endif
-        local_run(dp, W, L.smask, q0, ql, lane, y, tid, ring, B.ent + r * (size_t)B.eslots + q0, cnt, base);
+#ifdef FDCM_LAB
+        local_run(dp, W, L.smask, q0, ql, lane, y, tid, ring, B.ent + r * (size_t)B.eslots + q0, cnt, base, lab);
+#else
+        local_run(dp, W, L.smask, q0, ql, lane, y, tid, ring, B.ent + r * (size_t)B.eslots + q0, cnt, base, nullptr);
+#endif
         L.t_cnt[wave][lane] = cnt; L.t_base[wave][lane] = base;
         if (lane == 0) L.s_slot0[wave] = q0;
 #ifdef FDCM_LAB
@@ -1041,6 +1060,19 @@ void launch_sweep_balanced(hipStream_t st, const void* desc, float* vol, int W, 
                     cp.push_back((double)e[19] / (double)e[16]); cs.push_back(e[17] ? (double)e[20] / (double)e[17] : 0.0); ct.push_back((double)e[21]);
                     snp += (double)e[16]; scp += (double)e[19]; sns += (double)e[17]; scs += (double)e[20]; sct += (double)e[21];
                     if (e[21] > hct) { hct = e[21]; hp = e[16]; hcp = e[19]; hs = e[17]; hcs = e[20]; hf = e[18]; }
+                }
+                {  // the shared-cursor run: columns, ticks inside the pop loop statements, ticks of the whole local run
+                    std::vector<double> pc, oc, cols;
+                    double sp = 0, st = 0, sc = 0;
+                    for (long ch = 0; ch < nchunks; ++ch) for (int w = 0; w < kSeg; ++w) {
+                        const long long* e = &d[((size_t)ch * kSeg + w) * kLabN];
+                        if (!e[0] || e[16] || !e[17]) continue;
+                        pc.push_back((double)e[19] / (double)e[17]); oc.push_back((double)(e[21] - e[19]) / (double)e[17]); cols.push_back((double)e[17]);
+                        sp += (double)e[19]; st += (double)e[21]; sc += (double)e[17];
+                    }
+                    if (!pc.empty())
+                        fprintf(stderr, "[sweep lab] shared cursor: s_memtime ticks per column inside the pop loop: mean %.0f p50 %.0f p90 %.0f; outside it (descriptor, column value, push, eviction, the scan): mean %.0f p50 %.0f p90 %.0f; pop loop = %.0f %% of the local runs' ticks; columns per wave p50 %.0f\n",
+                                sp / sc, pct(pc, .5), pct(pc, .9), (st - sp) / sc, pct(oc, .5), pct(oc, .9), 100.0 * sp / st, pct(cols, .5));
                 }
                 if (!np.empty())
                     fprintf(stderr, "[sweep lab] lane cursors: passes per wave p50 %.0f p90 %.0f max %.0f; stagings p50 %.0f max %.0f; slow passes p50 %.0f max %.0f; s_memtime ticks per pass: mean %.0f p50 %.0f p90 %.0f; per staging: mean %.0f; share of the local run: passes %.0f %%, stagings %.0f %%; longest wave: %lld ticks = %lld passes (%lld ticks) + %lld stagings (%lld ticks), %lld slow\n",
