@@ -55,6 +55,7 @@ SYMBOLS = [
     ("fdcm_featuremap_device_volume", C.c_int, [_vp, C.POINTER(_vp)]),
     ("fdcm_featuremap_device_volume_stride", C.c_int, [_vp, C.POINTER(C.c_int64)]),
     ("fdcm_featuremap_last_timing", C.c_int, [_vp, C.POINTER(BuildTiming)]),
+    ("fdcm_featuremap_stage_timing", C.c_int, [_vp, C.c_int]),
     ("fdcm_featuremap_from_slices", C.c_int, [_fp, C.c_int64, _fp, C.c_int64, C.c_int64, _fp, C.POINTER(_vp)]),
     ("fdcm_featuremap_build_staged", C.c_int,
      [_fp, C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_int, C.c_int, C.POINTER(_vp)]),

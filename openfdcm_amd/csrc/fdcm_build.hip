@@ -724,6 +724,7 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after, bool 
     hipEvent_t* ev = fm->timing.ev;
 
     fm->build_host_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    fm->stage_events = fm->want_stage_events;  // (an event between two kernels costs a blocking frame 3 - 4 us: fdcm_featuremap_stage_timing)
     FDCM_HIP(hipEventRecord(ev[0], st));
     const long bitmap_words = ncols * HW64;
     if (!(fm->bitmap_clean && fm->bitmap_words == bitmap_words))
@@ -732,7 +733,7 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after, bool 
     if (fm->n_raster > 0)
         hipLaunchKernelGGL(k_seeds, dim3((unsigned)fm->n_raster), dim3(256), 0, st, d_raster,
                            fm->bitmap.as<unsigned long long>(), W, H, HW64);
-    FDCM_HIP(hipEventRecord(ev[1], st));
+    if (fm->stage_events) FDCM_HIP(hipEventRecord(ev[1], st));
     ColDesc* d_desc = fm->coldesc.as<ColDesc>();
     if (HW64 <= 64) {
         unsigned long long* bm = fm->bitmap.as<unsigned long long>();
@@ -748,7 +749,7 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after, bool 
                            fm->bitmap.as<unsigned long long>(), d_desc, W, HW64, ncols);
     }
     if (HW64 <= 64) { fm->bitmap_clean = true; fm->bitmap_words = bitmap_words; }  // one group of words per column: cleared in place
-    FDCM_HIP(hipEventRecord(ev[2], st));
+    if (fm->stage_events) FDCM_HIP(hipEventRecord(ev[2], st));
     if (fm->distance == FDCM_L1) {
         // both L1 sweeps with one pass over the volume: minima per (row, word), their prefix / suffix over the row's words, then word by word
         const int nwords = (W + 63) / 64;
@@ -765,7 +766,7 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after, bool 
     } else {
         launch_sweep_literal(st, d_desc, vol, W, H, HW64, nchunks, fm->stack.p);
     }
-    FDCM_HIP(hipEventRecord(ev[3], st));
+    if (fm->stage_events) FDCM_HIP(hipEventRecord(ev[3], st));
     const bool want_sqrt = fm->distance == FDCM_L2;
     if (stop_after >= 2) {
         const size_t nq = ivol_slice_floats(W, H);
@@ -794,7 +795,7 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after, bool 
         const size_t nel = fm->vol1_interleaved ? (size_t)m * ivol_slice_floats(W, H) : nvox;  // (padding elements: harmless)
         hipLaunchKernelGGL(k_sqrt, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, st, vol, nel);
     }
-    FDCM_HIP(hipEventRecord(ev[4], st));
+    if (fm->stage_events) FDCM_HIP(hipEventRecord(ev[4], st));
     if (stop_after >= 3) {
         const int chains = 2 * (W > H ? W : H);
         const int tab_stride = sh_tab_stride(W);
@@ -850,11 +851,13 @@ void finish_build(fdcm_featuremap* fm) {
     FDCM_HIP(hipStreamSynchronize(fm->stream));
     hipEvent_t* ev = fm->timing.ev;
     fdcm_build_timing& bt = fm->last_build;
-    FDCM_HIP(hipEventElapsedTime(&bt.seeds_ms, ev[0], ev[1]));
-    FDCM_HIP(hipEventElapsedTime(&bt.pass1_ms, ev[1], ev[2]));
-    FDCM_HIP(hipEventElapsedTime(&bt.pass2_ms, ev[2], ev[3]));
-    FDCM_HIP(hipEventElapsedTime(&bt.propagate_ms, ev[3], ev[4]));
-    FDCM_HIP(hipEventElapsedTime(&bt.integral_ms, ev[4], ev[5]));
+    if (fm->stage_events) {
+        FDCM_HIP(hipEventElapsedTime(&bt.seeds_ms, ev[0], ev[1]));
+        FDCM_HIP(hipEventElapsedTime(&bt.pass1_ms, ev[1], ev[2]));
+        FDCM_HIP(hipEventElapsedTime(&bt.pass2_ms, ev[2], ev[3]));
+        FDCM_HIP(hipEventElapsedTime(&bt.propagate_ms, ev[3], ev[4]));
+        FDCM_HIP(hipEventElapsedTime(&bt.integral_ms, ev[4], ev[5]));
+    }
     float span = 0.f;
     FDCM_HIP(hipEventElapsedTime(&span, ev[0], ev[5]));
     bt.total_ms = fm->build_host_ms + span;  // host preparation + the kernels' span on the device

@@ -202,6 +202,13 @@ int fdcm_featuremap_last_timing(const fdcm_featuremap* fm, fdcm_build_timing* t)
     });
 }
 
+int fdcm_featuremap_stage_timing(fdcm_featuremap* fm, int on) {
+    return guarded([&] {
+        require(fm != nullptr, "featuremap is null");
+        fm->want_stage_events = on != 0;
+    });
+}
+
 int fdcm_featuremap_from_slices(const float* keys, int64_t depth, const float* volume_host, int64_t width,
                                 int64_t height, const float scene_translation[2], fdcm_featuremap** out) {
     fdcm_featuremap* fm = nullptr;

@@ -123,6 +123,8 @@ struct fdcm_featuremap {
     long k2_cost_chunks = 0; int k2_cost_w = 0;  // the L2 sweep's per-chunk costs in `stack` are those of a build with this shape
     int off_m = 0, off_steps = 0;  // the group table in `offtab` is valid for this depth and feature width
     bool build_pending = false;  // the last build is queued on `stream` but has not been waited for
+    bool want_stage_events = true;  // fdcm_featuremap_stage_timing: record an event between the build's stages
+    bool stage_events = true;    // the last build did (fdcm_build_timing has per-stage times)
     bool shares_gpu = false;     // a frame slot of a pipeline with several frames in flight: other frames' kernels run beside this handle's
     float build_host_ms = 0.f;   // host time of that call up to its first kernel launch
     // geometry

@@ -131,6 +131,10 @@ class DeviceFeatureMap:
             toff.ctypes.data_as(C.POINTER(C.c_int64)), capi.fptr(scores)))
         return [scores[toff[i]:toff[i + 1]].copy() for i in range(len(trs))]
 
+    def stage_timing(self, on):
+        """Per-stage build times cost an event between the build's kernels; off: build_timing() has total_ms only."""
+        capi.check(capi.lib().fdcm_featuremap_stage_timing(self._h, 1 if on else 0))
+
     def build_timing(self):
         t = capi.BuildTiming()
         capi.check(capi.lib().fdcm_featuremap_last_timing(self._h, C.byref(t)))

@@ -568,6 +568,34 @@ def test_rebuilds_of_one_handle(amd, env):
     assert out.returncode == 0 and "24 rebuilds identical" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
 
+def test_stage_timing_switch_changes_events_not_results(amd):
+    """fdcm_featuremap_stage_timing(fm, 0): the builds record only their first and last event (the stage fields of the
+    timing are 0, total_ms is not) and the search of such a frame goes through the second stream of a handle that has the
+    GPU to itself -- the volume and the match list are what they were."""
+    from openfdcm_amd import synthetic, _capi
+    from openfdcm_amd.engine import DeviceFeatureMap, DeviceTemplates, search_raw
+    scene = synthetic.scene(256, 60, 5)
+    tmpls = synthetic.templates(40, 9, 256, 6)
+    ts = DeviceTemplates(tmpls)
+    dev = DeviceFeatureMap.build(scene, depth=12, coeff=5.0, padding=1.0, distance=O.L2)
+    want_vol = [dev.slice(k).copy() for k in range(12)]
+    want = np.array(search_raw(dev, ts, scene, 4, 4, _capi.BATCH_OPTIMIZE, 10), copy=True)
+    t_on = dev.build_timing()
+    assert t_on["pass2_ms"] > 0 and t_on["integral_ms"] > 0 and t_on["total_ms"] > 0
+    dev.stage_timing(False)
+    for _ in range(3):
+        dev.rebuild(scene)
+        got = np.array(search_raw(dev, ts, scene, 4, 4, _capi.BATCH_OPTIMIZE, 10), copy=True)
+        t_off = dev.build_timing()
+        assert t_off["pass2_ms"] == 0 and t_off["integral_ms"] == 0 and t_off["total_ms"] > 0
+        assert got.tobytes() == want.tobytes()
+    assert all(np.array_equal(dev.slice(k).view(np.uint32), want_vol[k].view(np.uint32)) for k in range(12))
+    dev.stage_timing(True)
+    dev.rebuild(scene)
+    assert dev.build_timing()["pass2_ms"] > 0
+    dev.close()
+
+
 def test_frame_pipeline_reports_a_failed_frame_and_keeps_going(amd):
     """A frame whose build fails (feature size above the supported maximum) is reported by its wait();
     the slot stays usable."""
