@@ -106,9 +106,10 @@ int fdcm_featuremap_slice(const fdcm_featuremap* fm, int64_t k, float* out_host)
 int fdcm_featuremap_device_volume(const fdcm_featuremap* fm, const float** device_ptr);
 int fdcm_featuremap_device_volume_stride(const fdcm_featuremap* fm, int64_t* floats_per_slice);
 int fdcm_featuremap_last_timing(const fdcm_featuremap* fm, fdcm_build_timing* t);
-/* Per-stage times cost a HIP event between every two kernels of the build (3 - 4 us each on a blocking frame).  on = 0: the
- * next builds record only their first and last event: fdcm_build_timing then carries total_ms alone (the stage fields
- * are 0).  Default: on.  No counterpart in the reference (it has no timers). */
+/* The device-side times of fdcm_build_timing / fdcm_search_timing cost a HIP event between every two kernels of the build and
+ * around the search (3 - 4 us each on a blocking frame).  on = 0: the next builds and searches of this handle record no
+ * events; their timings then carry the host time and the counters (candidates, evaluations) only, every device time is 0.
+ * Default: on.  No counterpart in the reference (it has no timers). */
 int fdcm_featuremap_stage_timing(fdcm_featuremap* fm, int on);
 /* Dt3Cpu(dt3map, sceneTranslation, featureSize) constructor (dt3cpu.h:55-58): adopt caller slices. */
 int fdcm_featuremap_from_slices(const float* keys, int64_t depth, const float* volume_host /* [k][x][y] */,

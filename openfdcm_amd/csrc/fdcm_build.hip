@@ -725,7 +725,7 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after, bool 
 
     fm->build_host_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     fm->stage_events = fm->want_stage_events;  // (an event between two kernels costs a blocking frame 3 - 4 us: fdcm_featuremap_stage_timing)
-    FDCM_HIP(hipEventRecord(ev[0], st));
+    if (fm->stage_events) FDCM_HIP(hipEventRecord(ev[0], st));
     const long bitmap_words = ncols * HW64;
     if (!(fm->bitmap_clean && fm->bitmap_words == bitmap_words))
         FDCM_HIP(hipMemsetAsync(fm->bitmap.p, 0, (size_t)bitmap_words * 8, st));
@@ -839,7 +839,7 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after, bool 
 #undef FDCM_INTEGRAL
     }
     fm->vol_stage = stop_after >= 3 ? 3 : (stop_after == 2 ? 2 : 1);
-    FDCM_HIP(hipEventRecord(ev[5], st));
+    if (fm->stage_events) FDCM_HIP(hipEventRecord(ev[5], st));
     FDCM_HIP(hipGetLastError());
     fm->build_pending = true;  // not waited for here: see finish_build
 }
@@ -859,7 +859,7 @@ void finish_build(fdcm_featuremap* fm) {
         FDCM_HIP(hipEventElapsedTime(&bt.integral_ms, ev[4], ev[5]));
     }
     float span = 0.f;
-    FDCM_HIP(hipEventElapsedTime(&span, ev[0], ev[5]));
+    if (fm->stage_events) FDCM_HIP(hipEventElapsedTime(&span, ev[0], ev[5]));
     bt.total_ms = fm->build_host_ms + span;  // host preparation + the kernels' span on the device
 }
 

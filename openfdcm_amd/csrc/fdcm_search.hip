@@ -797,7 +797,8 @@ void run_search(fdcm_featuremap* fm, const fdcm_templates* t, const float* scene
         FDCM_HIP(hipFuncSetAttribute(buf32 ? (const void*)k_search<true> : (const void*)k_search<false>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t* ev = fm->timing.ev;
-    FDCM_HIP(hipEventRecord(ev[6], st));
+    const bool timed = fm->want_stage_events;  // fdcm_featuremap_stage_timing(fm, 0): no events around the search either
+    if (timed) FDCM_HIP(hipEventRecord(ev[6], st));
     hipLaunchKernelGGL(k_pairs, dim3((unsigned)(((size_t)t->T * maxT + 255) / 256)), dim3(256), 0, sp, P);
     const long long n_slots = (long long)t->T * P.pairs_stride;
     static const bool no_worklist = getenv("FDCM_SEARCH_TEMPLATE_MAJOR") != nullptr;  // tuning override
@@ -936,7 +937,7 @@ void run_search(fdcm_featuremap* fm, const fdcm_templates* t, const float* scene
         hipLaunchKernelGGL(k_scatter, dim3((unsigned)nchunks), dim3(1024), 0, st, P.records, P.flags, ncand, d_counts, d_evsums,
                            nchunks, dst, P.counters, host_out, host_cnt);
     }
-    FDCM_HIP(hipEventRecord(ev[7], st));
+    if (timed) FDCM_HIP(hipEventRecord(ev[7], st));
     FDCM_HIP(hipGetLastError());
     unsigned long long hc[3] = {0, 0, 0};
     FDCM_HIP(hipStreamSynchronize(st));
@@ -944,7 +945,7 @@ void run_search(fdcm_featuremap* fm, const fdcm_templates* t, const float* scene
     std::memcpy(hc, out_host ? (const void*)(*out_host + ncand) : (const void*)fm->s_cnt.p, sizeof hc);
     *n_out = (int64_t)hc[2];
     fm->last_search.evaluations = (int64_t)hc[0];
-    FDCM_HIP(hipEventElapsedTime(&fm->last_search.kernel_ms, ev[6], ev[7]));
+    if (timed) FDCM_HIP(hipEventElapsedTime(&fm->last_search.kernel_ms, ev[6], ev[7]));
     // the search's own span on the device: kernels and download are one thing since the compaction writes the matches into
     // host memory itself (host preparation overlaps a build that is still running, and the wait for that build is not the
     // search's time)

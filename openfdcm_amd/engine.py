@@ -132,7 +132,7 @@ class DeviceFeatureMap:
         return [scores[toff[i]:toff[i + 1]].copy() for i in range(len(trs))]
 
     def stage_timing(self, on):
-        """Per-stage build times cost an event between the build's kernels; off: build_timing() has total_ms only."""
+        """Device-side times cost an event between the kernels; off: build_timing() / search_timing() carry host time and counters only."""
         capi.check(capi.lib().fdcm_featuremap_stage_timing(self._h, 1 if on else 0))
 
     def build_timing(self):
