@@ -880,6 +880,16 @@ __global__ void __launch_bounds__(kNT) k_sweep_balanced(const ColDesc* __restric
         if (tid == 0) B.cost[chunk] = (int)(wall_clock64() - t_start);
         return;
     }
+    // The kernel lasts as long as its heaviest workgroups (their chains, not the chip's throughput: DESIGN.md section 4), and a
+    // workgroup shares its CU's SIMDs with a lighter one: the heavy ones get the issue slots first.  Rank in the launch order
+    // when there is one (longest chunks of the previous build first), the slice's seeded columns otherwise.  (Config 2: 0.190 -
+    // 0.193 ms against 0.196 - 0.198 without, three alternating pairs on one box; config 3: no difference.)
+    {
+        const int heavy = B.order ? (blockIdx.x < 96u ? 3 : blockIdx.x < 224u ? 2 : blockIdx.x < 512u ? 1 : 0) : min(3, 4 * n / max(W, 1));
+        if (heavy == 3) __builtin_amdgcn_s_setprio(3);
+        else if (heavy == 2) __builtin_amdgcn_s_setprio(2);
+        else if (heavy == 1) __builtin_amdgcn_s_setprio(1);
+    }
     const int S = sweep_ranges(n, B.min_cols);  // ranges of this slice
     const Ring ring{reinterpret_cast<float*>(pool)};
 #ifdef FDCM_LAB
@@ -1029,8 +1039,14 @@ void launch_sweep_balanced(hipStream_t st, const void* desc, float* vol, int W, 
                     if (d[(size_t)ch * kSeg * kLabN]) ends.push_back({(end - t0) / 100.0, ch});
                 }
                 std::sort(ends.begin(), ends.end());
+                // .. and the blocks that live longest (second pass of the loop below)
+                std::vector<std::pair<double, long>> lives;
+                for (auto& en : ends) lives.push_back({en.first - (d[(size_t)en.second * kSeg * kLabN] - t0) / 100.0, en.second});
+                std::sort(lives.begin(), lives.end());
+                for (int pass = 0; pass < 2; ++pass)
                 for (size_t i = ends.size() > 6 ? ends.size() - 6 : 0; i < ends.size(); ++i) {
-                    const long ch = ends[i].second;
+                    const long ch = pass == 0 ? ends[i].second : lives[i].second;
+                    const char* what = pass == 0 ? "late" : "long";
                     double ph[7] = {0, 0, 0, 0, 0, 0, 0}, st0 = 1e30;
                     long long cols = 0, depth = 0, iters = 0, hbm = 0, refill = 0, owners = 0;
                     for (int w = 0; w < kSeg; ++w) {
@@ -1040,8 +1056,10 @@ void launch_sweep_balanced(hipStream_t st, const void* desc, float* vol, int W, 
                         cols = std::max(cols, e[9]); depth = std::max(depth, e[10]); iters = std::max(iters, e[12]); hbm = std::max(hbm, e[13]); refill = std::max(refill, e[14]);
                         owners = std::max(owners, e[11]);
                     }
-                    fprintf(stderr, "[sweep lab] late block %ld (slice %ld chunk %ld): %.1f -> %.1f us | local %.1f merge %.1f walk %.1f fill %.1f | columns %lld deepest %lld merge steps %lld (hbm %lld, refills %lld) owners %lld\n",
-                            ch, ch / HW64, ch % HW64, st0, ends[i].first, ph[0], ph[2], ph[4], ph[6], cols, depth, iters, hbm, refill, owners);
+                    double endt = 0;
+                    for (auto& en : ends) if (en.second == ch) endt = en.first;
+                    fprintf(stderr, "[sweep lab] %s block %ld (slice %ld chunk %ld): %.1f -> %.1f us | local %.1f merge %.1f walk %.1f fill %.1f | columns %lld deepest %lld merge steps %lld (hbm %lld, refills %lld) owners %lld\n",
+                            what, ch, ch / HW64, ch % HW64, st0, endt, ph[0], ph[2], ph[4], ph[6], cols, depth, iters, hbm, refill, owners);
                 }
             }
             {
