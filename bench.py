@@ -47,7 +47,7 @@ HBM_PEAK_GBS = 8000.0
 # distance transform = pass 1 writes V + pass 2 reads V and writes V (fused here: the sweep recomputes pass 1 from
 # V/16 of column descriptors and never materialises it); propagation reads V and writes V; line integral likewise.
 STAGE_BYTES_V = {"pass2_ms": 3.0, "propagate_ms": 2.0, "integral_ms": 2.0}
-STAGE_KERNELS = {"seeds_ms": "k_seeds", "pass1_ms": "k_coldesc",
+STAGE_KERNELS = {"seeds_ms": "k_seeds (feature sizes above 4096 px only; below, k_coldesc_tile draws the seeds itself)", "pass1_ms": "k_coldesc_tile",
                  "pass2_ms": "L2 / L2^2: k_sweep_balanced (k_pass2_l2 above 2896 px); L1: k_l1_word_mins + k_l1_carries + k_l1_word",
                  "propagate_ms": "k_propagate_reg", "integral_ms": "k_integral"}
 DIST_NAMES = {0: "L2", 1: "L2_SQUARED", 2: "L1"}

@@ -88,22 +88,42 @@ __global__ void __launch_bounds__(256) k_coldesc(unsigned long long* __restrict_
 // columns of a slice, SEG lanes (16 / 32 / 64: the words of a column) scan one column each, 64 / SEG columns per wave
 // pass, and the descriptors go through LDS so that every store covers the block's columns of one chunk (1 KB or 512 B
 // contiguous; the wave-per-column kernel writes 16 bytes every W * 16).
+// The seeds come straight from the slice's clipped lines (drawLines, drawing.h:111-125: k_seeds' points): every block
+// rasterises the lines of its slice that can reach its XT columns into a bitmap tile in LDS -- no seed bitmap in memory, no
+// launch of its own for a few thousand points, no atomics on HBM.
 template <int SEG, int XT>  // XT columns per block: 64, or 32 when a column has 64 words (32 KB of LDS instead of 64)
-__global__ void __launch_bounds__(256) k_coldesc_tile(unsigned long long* __restrict__ bitmap, ColDesc* __restrict__ desc,
-                                                      int W, int HW64, unsigned* __restrict__ colmask) {
-    extern __shared__ uint4 tile[];  // [word][XT columns], rows padded by one unit (bank spread)
+__global__ void __launch_bounds__(256) k_coldesc_tile(const RasterLine* __restrict__ lines, const int* __restrict__ slice_first,
+                                                      ColDesc* __restrict__ desc, int W, int H, int HW64, unsigned* __restrict__ colmask) {
+    extern __shared__ uint4 tile[];  // [word][XT columns], rows padded by one unit (bank spread); behind it the seed bits [word][XT]
     constexpr int STR = XT + 1;
+    unsigned long long* bits = reinterpret_cast<unsigned long long*>(tile + (size_t)HW64 * STR);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wi = lane & (SEG - 1), ci = lane / SEG;
     constexpr int CPP = 64 / SEG, CPW = XT / 4;  // columns per wave pass, columns per wave
     const long k = blockIdx.y;
     const int x0 = blockIdx.x * XT;
+    for (int i = threadIdx.x; i < HW64 * XT; i += 256) bits[i] = 0ull;
+    __syncthreads();
+    for (int li = slice_first[k]; li < slice_first[k + 1]; ++li) {
+        const RasterLine r = lines[li];
+        // the line's columns: between its two ends (a constant when xmode == 0), half a pixel of rounding on either side
+        const float xa = r.xmode == 0 ? r.xlow : fminf(r.xlow, r.xhigh), xb = r.xmode == 0 ? r.xlow : fmaxf(r.xlow, r.xhigh);
+        if (xb + 1.f < (float)x0 || xa - 1.f > (float)(x0 + XT - 1)) continue;
+        for (int i = threadIdx.x; i < r.n; i += 256) {
+            const float fx = lin_spaced_value(r.xmode, r.xlow, r.xhigh, r.xstep, r.n, i);
+            const long x = (long)roundf(fx);  // .round().cast<Eigen::Index>(): half away from zero
+            if (x < x0 || x >= x0 + XT || x >= W) continue;
+            const float fy = lin_spaced_value(r.ymode, r.ylow, r.yhigh, r.ystep, r.n, i);
+            const long y = (long)roundf(fy);
+            if (y < 0 || y >= H) continue;  // the reference would write out of bounds
+            atomicOr(&bits[(y >> 6) * XT + (int)(x - x0)], 1ull << (y & 63));
+        }
+    }
+    __syncthreads();
     for (int pass = 0; pass < CPW / CPP; ++pass) {
         const int xl = wave * CPW + pass * CPP + ci, x = x0 + xl;
         const bool valid = x < W && wi < HW64;
-        unsigned long long* bw = bitmap + ((size_t)k * W + (size_t)min(x, W - 1)) * HW64;
-        const unsigned long long word = valid ? bw[wi] : 0ull;
-        if (word) bw[wi] = 0ull;
+        const unsigned long long word = valid ? bits[wi * XT + xl] : 0ull;
         const int last_i = word ? wi * 64 + 63 - __clzll(word) : INT_MIN;
         const int first_i = word ? wi * 64 + (__ffsll((long long)word) - 1) : INT_MAX;
         int pmax = last_i, smin = first_i;  // inclusive scans inside the SEG lanes of a column
@@ -638,7 +658,7 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after, bool 
     const size_t npix = (size_t)W * H, nvox = npix * m;
     const long ncols = (long)m * W;
     fm->vol.reserve(std::max(nvox, (size_t)m * ivol_slice_floats(W, H)) * sizeof(float));  // the integrated volume comes back here, interleaved
-    fm->bitmap.reserve((size_t)ncols * HW64 * 8);
+    if (HW64 > 64) fm->bitmap.reserve((size_t)ncols * HW64 * 8);  // (feature sizes above 4096 only: k_seeds + k_coldesc)
     // every buffer of the build is reserved here, before the first kernel is queued: an allocation between two stages
     // (a handle's first build) stalls the host for 0.5 - 1 ms while the GPU idles inside the stage events' span
     if (stop_after >= 2) fm->ivol.reserve((size_t)m * ivol_slice_floats(W, H) * sizeof(float));
@@ -698,7 +718,8 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after, bool 
     fm->off_prop = align16(plan.raster.size() * sizeof(RasterLine));
     fm->off_integral = fm->off_prop + align16(plan.prop.size() * sizeof(PropStep));
     fm->off_keys = fm->off_integral + align16(plan.integral.size() * sizeof(IntegralDesc));
-    fm->off_cost = fm->off_keys + align16(plan.keys.size() * sizeof(float));
+    fm->off_slice = fm->off_keys + align16(plan.keys.size() * sizeof(float));
+    fm->off_cost = fm->off_slice + align16(plan.slice_first.size() * sizeof(int32_t));
     const size_t blob = fm->off_cost + ((proxy_order || reserve_only) ? align16((size_t)nchunks * sizeof(int32_t)) : 0);
     fm->stage.reserve(blob);
     fm->plan.reserve(blob);
@@ -711,6 +732,7 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after, bool 
     std::memcpy(hs + fm->off_prop, plan.prop.data(), plan.prop.size() * sizeof(PropStep));
     std::memcpy(hs + fm->off_integral, plan.integral.data(), plan.integral.size() * sizeof(IntegralDesc));
     std::memcpy(hs + fm->off_keys, plan.keys.data(), plan.keys.size() * sizeof(float));
+    std::memcpy(hs + fm->off_slice, plan.slice_first.data(), plan.slice_first.size() * sizeof(int32_t));
     if (proxy_order) std::memcpy(hs + fm->off_cost, proxy_cost.data(), proxy_cost.size() * sizeof(int32_t));
     FDCM_HIP(hipMemcpyAsync(fm->plan.p, hs, blob, hipMemcpyHostToDevice, st));
     if (proxy_order) launch_sweep_order(st, (const int*)((const char*)fm->plan.p + fm->off_cost), (int)nchunks, order_dst);
@@ -726,29 +748,29 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after, bool 
     fm->build_host_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     fm->stage_events = fm->want_stage_events;  // (an event between two kernels costs a blocking frame 3 - 4 us: fdcm_featuremap_stage_timing)
     if (fm->stage_events) FDCM_HIP(hipEventRecord(ev[0], st));
-    const long bitmap_words = ncols * HW64;
-    if (!(fm->bitmap_clean && fm->bitmap_words == bitmap_words))
-        FDCM_HIP(hipMemsetAsync(fm->bitmap.p, 0, (size_t)bitmap_words * 8, st));
-    fm->bitmap_clean = false;
-    if (fm->n_raster > 0)
-        hipLaunchKernelGGL(k_seeds, dim3((unsigned)fm->n_raster), dim3(256), 0, st, d_raster,
-                           fm->bitmap.as<unsigned long long>(), W, H, HW64);
-    if (fm->stage_events) FDCM_HIP(hipEventRecord(ev[1], st));
     ColDesc* d_desc = fm->coldesc.as<ColDesc>();
     if (HW64 <= 64) {
-        unsigned long long* bm = fm->bitmap.as<unsigned long long>();
+        // the tile kernel rasterises the seeds of its columns itself (LDS): no bitmap, no k_seeds, no stage of its own
+        fm->seeds_fused = true;
+        const int* d_first = (const int*)(dp + fm->off_slice);
         const int XT = HW64 > 32 ? 32 : 64;
         const dim3 grid((unsigned)((W + XT - 1) / XT), (unsigned)m);
-        const size_t lds = (size_t)HW64 * (XT + 1) * sizeof(uint4);
+        const size_t lds = (size_t)HW64 * (XT + 1) * sizeof(uint4) + (size_t)HW64 * XT * 8;
         unsigned* cm = (unsigned*)fm->colmask.p;
-        if (HW64 <= 16) hipLaunchKernelGGL((k_coldesc_tile<16, 64>), grid, dim3(256), lds, st, bm, d_desc, W, HW64, cm);
-        else if (HW64 <= 32) hipLaunchKernelGGL((k_coldesc_tile<32, 64>), grid, dim3(256), lds, st, bm, d_desc, W, HW64, cm);
-        else hipLaunchKernelGGL((k_coldesc_tile<64, 32>), grid, dim3(256), lds, st, bm, d_desc, W, HW64, cm);
+        if (HW64 <= 16) hipLaunchKernelGGL((k_coldesc_tile<16, 64>), grid, dim3(256), lds, st, d_raster, d_first, d_desc, W, H, HW64, cm);
+        else if (HW64 <= 32) hipLaunchKernelGGL((k_coldesc_tile<32, 64>), grid, dim3(256), lds, st, d_raster, d_first, d_desc, W, H, HW64, cm);
+        else hipLaunchKernelGGL((k_coldesc_tile<64, 32>), grid, dim3(256), lds, st, d_raster, d_first, d_desc, W, H, HW64, cm);
     } else {
+        fm->seeds_fused = false;
+        const long bitmap_words = ncols * HW64;
+        FDCM_HIP(hipMemsetAsync(fm->bitmap.p, 0, (size_t)bitmap_words * 8, st));
+        if (fm->n_raster > 0)
+            hipLaunchKernelGGL(k_seeds, dim3((unsigned)fm->n_raster), dim3(256), 0, st, d_raster,
+                               fm->bitmap.as<unsigned long long>(), W, H, HW64);
+        if (fm->stage_events) FDCM_HIP(hipEventRecord(ev[1], st));
         hipLaunchKernelGGL(k_coldesc, dim3((unsigned)((ncols + 3) / 4)), dim3(256), 0, st,
                            fm->bitmap.as<unsigned long long>(), d_desc, W, HW64, ncols);
     }
-    if (HW64 <= 64) { fm->bitmap_clean = true; fm->bitmap_words = bitmap_words; }  // one group of words per column: cleared in place
     if (fm->stage_events) FDCM_HIP(hipEventRecord(ev[2], st));
     if (fm->distance == FDCM_L1) {
         // both L1 sweeps with one pass over the volume: minima per (row, word), their prefix / suffix over the row's words, then word by word
@@ -852,8 +874,12 @@ void finish_build(fdcm_featuremap* fm) {
     hipEvent_t* ev = fm->timing.ev;
     fdcm_build_timing& bt = fm->last_build;
     if (fm->stage_events) {
-        FDCM_HIP(hipEventElapsedTime(&bt.seeds_ms, ev[0], ev[1]));
-        FDCM_HIP(hipEventElapsedTime(&bt.pass1_ms, ev[1], ev[2]));
+        if (fm->seeds_fused) {
+            FDCM_HIP(hipEventElapsedTime(&bt.pass1_ms, ev[0], ev[2]));  // (seeds_ms stays 0: k_coldesc_tile draws them)
+        } else {
+            FDCM_HIP(hipEventElapsedTime(&bt.seeds_ms, ev[0], ev[1]));
+            FDCM_HIP(hipEventElapsedTime(&bt.pass1_ms, ev[1], ev[2]));
+        }
         FDCM_HIP(hipEventElapsedTime(&bt.pass2_ms, ev[2], ev[3]));
         FDCM_HIP(hipEventElapsedTime(&bt.propagate_ms, ev[3], ev[4]));
         FDCM_HIP(hipEventElapsedTime(&bt.integral_ms, ev[4], ev[5]));

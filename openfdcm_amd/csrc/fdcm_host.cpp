@@ -173,7 +173,12 @@ void make_build_plan(const float* lines, int64_t n, int64_t depth, float coeff, 
         per_slice[k].push_back(raster_descriptor(l, k));
         plan.boxes.push_back(LineBox{k, std::min(l[0], l[2]), std::max(l[0], l[2]), std::min(l[1], l[3]), std::max(l[1], l[3])});
     }
-    for (auto& v : per_slice) plan.raster.insert(plan.raster.end(), v.begin(), v.end());
+    plan.slice_first.assign((size_t)m + 1, 0);
+    for (int k = 0; k < m; ++k) {
+        plan.slice_first[k] = (int32_t)plan.raster.size();
+        plan.raster.insert(plan.raster.end(), per_slice[k].begin(), per_slice[k].end());
+    }
+    plan.slice_first[m] = (int32_t)plan.raster.size();
     // propagateOrientation step table, dt3cpu.cpp:86-106
     {
         const int fwd = static_cast<int>(std::ceil(1.5 * m));

@@ -68,7 +68,8 @@ struct BuildPlan {
     int64_t W = 0, H = 0, m = 0;
     float tx = 0, ty = 0;
     std::vector<float> keys;
-    std::vector<RasterLine> raster;
+    std::vector<RasterLine> raster;      // ordered by slice
+    std::vector<int32_t> slice_first;    // m + 1: the lines of slice k are raster[slice_first[k] .. slice_first[k + 1])
     std::vector<PropStep> prop;
     std::vector<IntegralDesc> integral;
     std::vector<LineBox> boxes;       // the clipped lines' bounding boxes (what sweep_cost_proxy works from)
@@ -118,11 +119,10 @@ struct fdcm_featuremap {
     int64_t depth_param = 0;
     float coeff = 0, padding = 0;
     int distance = 0;
-    bool bitmap_clean = false;   // k_coldesc left the seed bitmap zeroed (it clears what it reads)
-    long bitmap_words = 0;       // size the bitmap had then
     long k2_cost_chunks = 0; int k2_cost_w = 0;  // the L2 sweep's per-chunk costs in `stack` are those of a build with this shape
     int off_m = 0, off_steps = 0;  // the group table in `offtab` is valid for this depth and feature width
     bool build_pending = false;  // the last build is queued on `stream` but has not been waited for
+    bool seeds_fused = false;    // the last build drew its seeds inside k_coldesc_tile (no seeds stage, no event for it)
     bool want_stage_events = true;  // fdcm_featuremap_stage_timing: record an event between the build's stages
     bool stage_events = true;    // the last build did (fdcm_build_timing has per-stage times)
     bool shares_gpu = false;     // a frame slot of a pipeline with several frames in flight: other frames' kernels run beside this handle's
@@ -149,7 +149,7 @@ struct fdcm_featuremap {
     fdcm::DevBuf stack;    // K2 scratch: per row a (v, f, z) stack of W entries
     fdcm::DevBuf plan;     // RasterLine[] | PropStep[] | IntegralDesc[] | keys[]
     fdcm::PinnedBuf stage; // host staging for the plan
-    size_t off_raster = 0, off_prop = 0, off_integral = 0, off_keys = 0, off_cost = 0;
+    size_t off_raster = 0, off_prop = 0, off_integral = 0, off_keys = 0, off_slice = 0, off_cost = 0;
     int64_t n_raster = 0, n_prop = 0;
     // search workspaces
     fdcm::DevBuf s_scene;   // scene lines + sorted lengths + sorted idx
