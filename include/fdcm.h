@@ -65,11 +65,12 @@ typedef struct fdcm_featuremap_info {
 /* Per-stage device times of the last build, in milliseconds (HIP events on the build stream). */
 typedef struct fdcm_build_timing {
     float total_ms;     /* host preparation + the kernels' span on the device */
-    float seeds_ms;     /* K0: rasterise scene lines into the seed bitmap */
+    float seeds_ms;     /* K0: rasterise scene lines into the seed bitmap (feature sizes above 4096 only: below, K1 draws the seeds itself) */
     float pass1_ms;     /* K1: 1-D distance along y */
     float pass2_ms;     /* K2: in-place lower-envelope pass along x (L2/L2^2) or L1 sweeps */
     float propagate_ms; /* K3: orientation propagation (+ sqrt for L2) */
     float integral_ms;  /* K4: directional line integral */
+    float span_ms;      /* the kernels' span on the device alone (first to last event; 0 without events) */
 } fdcm_build_timing;
 
 typedef struct fdcm_search_timing {
@@ -107,9 +108,10 @@ int fdcm_featuremap_device_volume(const fdcm_featuremap* fm, const float** devic
 int fdcm_featuremap_device_volume_stride(const fdcm_featuremap* fm, int64_t* floats_per_slice);
 int fdcm_featuremap_last_timing(const fdcm_featuremap* fm, fdcm_build_timing* t);
 /* The device-side times of fdcm_build_timing / fdcm_search_timing cost a HIP event between every two kernels of the build and
- * around the search (3 - 4 us each on a blocking frame).  on = 0: the next builds and searches of this handle record no
- * events; their timings then carry the host time and the counters (candidates, evaluations) only, every device time is 0.
- * Default: on.  No counterpart in the reference (it has no timers). */
+ * around the search (3 - 5 us each on a blocking frame).  on = 1 (default): per-stage times.  on = 2: events around the
+ * build and around the search only (total_ms and the search's kernel_ms; the stage fields are 0).  on = 0: no events: the
+ * timings carry the host time and the counters (candidates, evaluations) only, every device time is 0.
+ * No counterpart in the reference (it has no timers). */
 int fdcm_featuremap_stage_timing(fdcm_featuremap* fm, int on);
 /* Dt3Cpu(dt3map, sceneTranslation, featureSize) constructor (dt3cpu.h:55-58): adopt caller slices. */
 int fdcm_featuremap_from_slices(const float* keys, int64_t depth, const float* volume_host /* [k][x][y] */,

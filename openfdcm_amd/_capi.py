@@ -30,7 +30,7 @@ class FeaturemapInfo(C.Structure):
 
 class BuildTiming(C.Structure):
     _fields_ = [("total_ms", C.c_float), ("seeds_ms", C.c_float), ("pass1_ms", C.c_float),
-                ("pass2_ms", C.c_float), ("propagate_ms", C.c_float), ("integral_ms", C.c_float)]
+                ("pass2_ms", C.c_float), ("propagate_ms", C.c_float), ("integral_ms", C.c_float), ("span_ms", C.c_float)]
 
 
 class SearchTiming(C.Structure):

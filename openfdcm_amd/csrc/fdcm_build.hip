@@ -746,8 +746,9 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after, bool 
     hipEvent_t* ev = fm->timing.ev;
 
     fm->build_host_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    fm->stage_events = fm->want_stage_events;  // (an event between two kernels costs a blocking frame 3 - 4 us: fdcm_featuremap_stage_timing)
-    if (fm->stage_events) FDCM_HIP(hipEventRecord(ev[0], st));
+    fm->stage_events = fm->want_stage_events == 1;  // (an event between two kernels costs a blocking frame 3 - 5 us: fdcm_featuremap_stage_timing)
+    fm->total_events = fm->want_stage_events != 0;
+    if (fm->total_events) FDCM_HIP(hipEventRecord(ev[0], st));
     ColDesc* d_desc = fm->coldesc.as<ColDesc>();
     if (HW64 <= 64) {
         // the tile kernel rasterises the seeds of its columns itself (LDS): no bitmap, no k_seeds, no stage of its own
@@ -861,7 +862,7 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after, bool 
 #undef FDCM_INTEGRAL
     }
     fm->vol_stage = stop_after >= 3 ? 3 : (stop_after == 2 ? 2 : 1);
-    if (fm->stage_events) FDCM_HIP(hipEventRecord(ev[5], st));
+    if (fm->total_events) FDCM_HIP(hipEventRecord(ev[5], st));
     FDCM_HIP(hipGetLastError());
     fm->build_pending = true;  // not waited for here: see finish_build
 }
@@ -885,7 +886,8 @@ void finish_build(fdcm_featuremap* fm) {
         FDCM_HIP(hipEventElapsedTime(&bt.integral_ms, ev[4], ev[5]));
     }
     float span = 0.f;
-    if (fm->stage_events) FDCM_HIP(hipEventElapsedTime(&span, ev[0], ev[5]));
+    if (fm->total_events) FDCM_HIP(hipEventElapsedTime(&span, ev[0], ev[5]));
+    bt.span_ms = span;
     bt.total_ms = fm->build_host_ms + span;  // host preparation + the kernels' span on the device
 }
 

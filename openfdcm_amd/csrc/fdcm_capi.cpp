@@ -205,7 +205,8 @@ int fdcm_featuremap_last_timing(const fdcm_featuremap* fm, fdcm_build_timing* t)
 int fdcm_featuremap_stage_timing(fdcm_featuremap* fm, int on) {
     return guarded([&] {
         require(fm != nullptr, "featuremap is null");
-        fm->want_stage_events = on != 0;
+        require(on >= 0 && on <= 2, "stage timing: 0 (off), 1 (per stage) or 2 (totals only)");
+        fm->want_stage_events = on;
     });
 }
 

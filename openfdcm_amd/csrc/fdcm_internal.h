@@ -123,8 +123,9 @@ struct fdcm_featuremap {
     int off_m = 0, off_steps = 0;  // the group table in `offtab` is valid for this depth and feature width
     bool build_pending = false;  // the last build is queued on `stream` but has not been waited for
     bool seeds_fused = false;    // the last build drew its seeds inside k_coldesc_tile (no seeds stage, no event for it)
-    bool want_stage_events = true;  // fdcm_featuremap_stage_timing: record an event between the build's stages
-    bool stage_events = true;    // the last build did (fdcm_build_timing has per-stage times)
+    int want_stage_events = 1;   // fdcm_featuremap_stage_timing: 0 no events, 1 an event between the build's stages, 2 around the build and the search only
+    bool stage_events = true;    // the last build recorded its stages (fdcm_build_timing has per-stage times)
+    bool total_events = true;    // .. its first and last event (total_ms has the device span)
     bool shares_gpu = false;     // a frame slot of a pipeline with several frames in flight: other frames' kernels run beside this handle's
     float build_host_ms = 0.f;   // host time of that call up to its first kernel launch
     // geometry

@@ -797,7 +797,7 @@ void run_search(fdcm_featuremap* fm, const fdcm_templates* t, const float* scene
         FDCM_HIP(hipFuncSetAttribute(buf32 ? (const void*)k_search<true> : (const void*)k_search<false>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t* ev = fm->timing.ev;
-    const bool timed = fm->want_stage_events;  // fdcm_featuremap_stage_timing(fm, 0): no events around the search either
+    const bool timed = fm->want_stage_events != 0;  // fdcm_featuremap_stage_timing(fm, 0): no events around the search either
     if (timed) FDCM_HIP(hipEventRecord(ev[6], st));
     hipLaunchKernelGGL(k_pairs, dim3((unsigned)(((size_t)t->T * maxT + 255) / 256)), dim3(256), 0, sp, P);
     const long long n_slots = (long long)t->T * P.pairs_stride;

@@ -132,8 +132,9 @@ class DeviceFeatureMap:
         return [scores[toff[i]:toff[i + 1]].copy() for i in range(len(trs))]
 
     def stage_timing(self, on):
-        """Device-side times cost an event between the kernels; off: build_timing() / search_timing() carry host time and counters only."""
-        capi.check(capi.lib().fdcm_featuremap_stage_timing(self._h, 1 if on else 0))
+        """Device-side times cost an event between the kernels: True / 1 per-stage times (default), 2 the build's and the
+        search's spans only, False / 0 none (build_timing() / search_timing() carry host time and counters only)."""
+        capi.check(capi.lib().fdcm_featuremap_stage_timing(self._h, int(on)))
 
     def build_timing(self):
         t = capi.BuildTiming()

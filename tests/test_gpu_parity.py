@@ -589,9 +589,16 @@ def test_stage_timing_switch_changes_events_not_results(amd):
         assert t_off["pass2_ms"] == 0 and t_off["integral_ms"] == 0 and s_off["kernel_ms"] == 0 and s_off["evaluations"] > 0
         assert got.tobytes() == want.tobytes()
     assert all(np.array_equal(dev.slice(k).view(np.uint32), want_vol[k].view(np.uint32)) for k in range(12))
+    dev.stage_timing(2)  # the build's and the search's spans only
+    dev.rebuild(scene)
+    got = np.array(search_raw(dev, ts, scene, 4, 4, _capi.BATCH_OPTIMIZE, 10), copy=True)
+    t2, s2 = dev.build_timing(), dev.search_timing()
+    assert t2["pass2_ms"] == 0 and t2["span_ms"] > 0 and t2["total_ms"] >= t2["span_ms"] and s2["kernel_ms"] > 0
+    assert got.tobytes() == want.tobytes()
     dev.stage_timing(True)
     dev.rebuild(scene)
-    assert dev.build_timing()["pass2_ms"] > 0
+    t1 = dev.build_timing()
+    assert t1["pass2_ms"] > 0 and t1["span_ms"] >= t1["pass2_ms"]
     dev.close()
 
 
