@@ -96,7 +96,7 @@ __device__ __forceinline__ int select_column(const unsigned long long* smask, in
 // ---- the literal construction over the seeded columns [q0, ql] of the slice, bottom = q0 (imgproc.h:100-121)
 // Stack entries in registers and in the ring are (float(2 v), P = f[v] + v^2, z): the numerator of imgproc.h:111,
 // ((f[q] + q^2) - f[v]) - v^2, is the exact integer P_q - P_v whatever the order (every term is an integer below 2^24), so
-// the test takes one subtraction, and f[v] = P - v^2 comes back exactly where an entry leaves for memory.
+// the test takes one subtraction; memory holds the same three numbers (f[v] = P - v^2 comes back exactly where the owner walk wants it).
 __device__ __forceinline__ EnvEntry to_mem(const float4& e) { return EnvEntry{e.x, e.y, e.z}; }
 __device__ __forceinline__ float4 from_mem(const EnvEntry& e) { return make_float4(e.v2, e.P, e.z, 0.f); }
 // ---- end of a local run: the top joins the entries; everything in the ring also goes to HBM (the ring keeps its content
