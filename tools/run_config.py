@@ -37,12 +37,13 @@ def main():
         stages.append(dev.build_timing())
     avg = {k: float(np.median([s[k] for s in stages])) for k in stages[0]}
     V = 4.0 * cfg["depth"] * cfg["S"] ** 2
-    kern = sum(avg[k] for k in avg if k != "total_ms")
+    stages = ("seeds_ms", "pass1_ms", "pass2_ms", "propagate_ms", "integral_ms")
+    kern = sum(avg[k] for k in stages)  # (with an event between the stages: 3 - 5 us each; span_ms is first to last event)
     out = {"config": args.config, "V_MB": V / 1e6, "stage_ms": avg, "kernels_ms": kern,
            "GBps_7V": 7 * V / (kern * 1e-3) / 1e9, "frac_of_8TBps": 7 * V / (kern * 1e-3) / 8e12}
     if args.perturb:
         def kern(t):
-            return sum(v for k, v in t.items() if k != "total_ms")
+            return sum(t[k] for k in stages)
         firsts = []
         for i in range(5):  # fresh handles: no history
             d2 = DeviceFeatureMap.build(synthetic.scene(cfg["S"], cfg["scene_lines"], 1 + i), depth=cfg["depth"], coeff=5.0,
