@@ -156,10 +156,14 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: the config's per-GPU template count on every rank; strong: the config's TOTAL template count "
                          "(BASELINE.md section 5: 1/2/4/8 GPUs on config 2' itself) cut into N shards")
-    ap.add_argument("--scenes", type=int, default=None,
-                    help="distinct scenes cycled through the frames (seeds 1..n; default 1, 4 with --force-dist).  With more "
-                         "than one, EVERY collected frame of the timed region is checked against the oracle's records of its "
-                         "own scene after the run (a frame/slot mix-up in the pipeline or the gather would show)")
+    ap.add_argument("--scenes", type=int, default=4,
+                    help="distinct scenes cycled through the frames, in the timed region and in the blocking frames the roofline "
+                         "is measured on (seeds 1..n; default 4: a caller builds a new scene every frame, matching.cpp:116-130).  "
+                         "With more than one, EVERY collected frame of the timed region is checked against the oracle's records of "
+                         "its own scene after the run (a frame/slot mix-up in the pipeline or the gather would show)")
+    ap.add_argument("--api-frames", type=int, default=20,
+                    help="frames of the reference's Python call sequence (build_cpu_featuremap -> search -> get_template_lengths -> "
+                         "penalize -> sort_matches through `import openfdcm_amd as openfdcm` only) timed after the run (0 = skip)")
     ap.add_argument("--cpu-reps", type=int, default=5, help="CPU baseline runs (median)")
     ap.add_argument("--cpu-warmup", type=int, default=1, help="0: no warm-up build of the CPU baseline (the large configs: a build takes a minute)")
     args = ap.parse_args()
@@ -189,7 +193,7 @@ def main():
 
     cfg = dict(synthetic.CONFIGS[args.config])
     per_gpu = args.templates or PER_GPU[args.config]
-    n_scenes = args.scenes or (4 if args.force_dist else 1)
+    n_scenes = max(1, args.scenes)
     scenes = [synthetic.scene(cfg["S"], cfg["scene_lines"], 1 + i) for i in range(n_scenes)]
     scene = scenes[0]
     # weak scaling: every rank owns `per_gpu` templates of a global list of world * per_gpu;
@@ -274,37 +278,93 @@ def main():
     n_matches = total_matches / max(1, args.steps)
     gpu_last = None if acc["last"] is None else np.array(acc["last"], copy=True)
 
-    # untimed extra: blocking frames (one in flight, the GPU to itself) for the roofline objects
+    # untimed extra: blocking frames (one in flight, the GPU to itself) for the roofline objects.  The frames cycle the
+    # same scenes as the timed region, so every build is a NEW scene for its handle (the launch order and the priority
+    # of heavy workgroups come from the handle's previous build, i.e. from another scene); the same-scene figure, where
+    # that history fits, is kept beside it.
     single = None
     if rank == 0 and args.single_frames > 0:  # (N > 1: the other ranks wait at the closing barrier meanwhile)
         fm = DeviceFeatureMap.build(scene, depth=cfg["depth"], coeff=5.0, padding=1.0, distance=cfg["distance"])
+        count = [0]
+
+        def blocking_frame(cycle=True):
+            sc = scenes[count[0] % n_scenes] if cycle else scene
+            count[0] += 1
+            fm.rebuild(sc)
+            return search_raw(fm, searcher.tset, sc, 4, 4, _capi.BATCH_OPTIMIZE, 10, searcher.begin)
+
         for _ in range(5):
-            fm.rebuild(scene)
-            search_raw(fm, searcher.tset, scene, 4, 4, _capi.BATCH_OPTIMIZE, 10, searcher.begin)
+            blocking_frame()
         st = {k: [] for k in stage_keys}
         sk, wall = [], []
         for _ in range(args.single_frames):  # per-stage times: an event between every two kernels of the build
-            fm.rebuild(scene)
-            search_raw(fm, searcher.tset, scene, 4, 4, _capi.BATCH_OPTIMIZE, 10, searcher.begin)
+            blocking_frame()
             bt = fm.build_timing()
             for k in st:
                 st[k].append(bt[k])
             sk.append(fm.search_timing()["kernel_ms"])
         fm.stage_timing(2)  # the build's span without the events between its stages (3 - 5 us each): first and last event only
-        spans = []
+        spans, totals, same = [], [], []
         for _ in range(args.single_frames):
-            fm.rebuild(scene)
-            search_raw(fm, searcher.tset, scene, 4, 4, _capi.BATCH_OPTIMIZE, 10, searcher.begin)
-            spans.append(fm.build_timing()["span_ms"])
+            blocking_frame()
+            bt = fm.build_timing()
+            spans.append(bt["span_ms"])
+            totals.append(bt["total_ms"])
+        for i in range(args.single_frames + 3):  # the same scene over and over (3 frames to settle its history)
+            blocking_frame(cycle=False)
+            if i >= 3:
+                same.append(fm.build_timing()["span_ms"])
         fm.stage_timing(False)  # the frame as a caller runs it: no events at all, wall clock around the two calls
         for _ in range(args.single_frames + 3):
             t1 = time.perf_counter()
-            fm.rebuild(scene)
-            search_raw(fm, searcher.tset, scene, 4, 4, _capi.BATCH_OPTIMIZE, 10, searcher.begin)
+            blocking_frame()
             wall.append(time.perf_counter() - t1)
         single = {"stage_ms": {k: float(np.mean(v)) for k, v in st.items()}, "search_kernel_ms": float(np.mean(sk)),
-                  "span_ms": float(np.mean(spans)), "frame_ms": float(np.mean(wall[3:])) * 1e3}
+                  "span_ms": float(np.mean(spans)), "same_scene_span_ms": float(np.mean(same)), "build_total_ms": float(np.mean(totals)),
+                  "frame_ms": float(np.mean(wall[3:])) * 1e3}
         fm.close()
+
+    # untimed extra: the reference's Python call sequence, through `import openfdcm_amd as openfdcm` only
+    # (python/src/matching.cpp:116-130,279-307): what a drop-in caller gets per blocking frame
+    api = None
+    if rank == 0 and args.api_frames > 0:
+        import openfdcm_amd as openfdcm
+        my_templates = list(all_templates[searcher.begin:searcher.end])
+        params = openfdcm.Dt3CpuParameters(depth=cfg["depth"], dt3Coeff=5.0, padding=1.0, distance=openfdcm.distance(cfg["distance"]))
+        matcher, strategy, optimizer = openfdcm.DefaultMatch(), openfdcm.DefaultSearch(4, 4), openfdcm.BatchOptimize(10)
+        penalty = openfdcm.ExponentialPenalty(tau=1.5)
+        parts = {k: [] for k in ("build_cpu_featuremap", "search", "get_template_lengths", "penalize", "sort_matches")}
+        api_wall, api_n, api_last = [], 0, None
+        for i in range(args.api_frames + 3):
+            sc = scenes[i % n_scenes]
+            t = [time.perf_counter()]
+            featuremap = openfdcm.build_cpu_featuremap(sc, params)
+            t.append(time.perf_counter())
+            matches = openfdcm.search(matcher, strategy, optimizer, featuremap, my_templates, sc)
+            t.append(time.perf_counter())
+            lengths = openfdcm.get_template_lengths(my_templates)
+            t.append(time.perf_counter())
+            penalised = openfdcm.penalize(penalty, matches, lengths)
+            t.append(time.perf_counter())
+            best = openfdcm.sort_matches(penalised)
+            t.append(time.perf_counter())
+            if i >= 3:
+                api_wall.append(t[-1] - t[0])
+                api_n += len(matches)
+                for k, (x, y) in zip(parts, zip(t, t[1:])):
+                    parts[k].append(y - x)
+            api_last = (i % n_scenes, matches, best)
+        t1 = time.perf_counter()
+        checksum = 0.0
+        for m in api_last[2]:
+            checksum += m.score
+        iterate_ms = (time.perf_counter() - t1) * 1e3
+        api = {"frame_ms": float(np.mean(api_wall)) * 1e3, "matches_per_s": api_n / float(np.sum(api_wall)),
+               "calls_ms": {k: round(float(np.mean(v)) * 1e3, 4) for k, v in parts.items()},
+               "iterate_all_matches_ms": iterate_ms, "frames": args.api_frames, "last": api_last}
+        del featuremap
+        openfdcm.clear_featuremap_pool()
+        openfdcm.clear_template_cache()
 
     out, gate_failed = None, False
     if rank == 0:
@@ -336,8 +396,9 @@ def main():
                                  "slowest": (lambda i: {"frame": int(i), "latency": frame_log[i][0], "build_span": frame_log[i][1],
                                                         "search_span": frame_log[i][2], "search_kernels": frame_log[i][3]})(int(np.argmax(lat)))},
             "templates_per_s": total_templates * K / elapsed,
-            # BASELINE.json's "DT3 build ms": the build's kernels with the GPU to itself (set below from the blocking frames;
-            # the span of a build inside the timed region, where F frames share the CUs, is in_timed_region.dt3_build_span_ms)
+            # BASELINE.json's "DT3 build ms": one blocking build with the GPU to itself, host preparation included (set below from
+            # the blocking frames; the span of a build inside the timed region, where F frames share the CUs, is
+            # in_timed_region.dt3_build_span_ms)
             "dt3_build_ms": None,
             "in_timed_region": {"note": f"per-launch HIP-event times with {F} frames in flight: launches of concurrent "
                                         "frames share the CUs, so these exceed ms_per_step and the blocking figures",
@@ -361,7 +422,10 @@ def main():
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                                "traffic": traffic, "traffic_source": traffic_src,
                                "algorithmic_bytes_per_launch": 7.0 * V, "avg_launch_ms": span,
-                               "measured": f"{args.single_frames} blocking frames after the timed region (GPU to itself), HIP events on the "
+                               "same_scene_ms": single["same_scene_span_ms"], "distinct_scenes": n_scenes,
+                               "measured": f"{args.single_frames} blocking frames after the timed region (GPU to itself) cycling the {n_scenes} "
+                                           "scenes of the timed region, so each build is a new scene for its handle (same_scene_ms: one scene "
+                                           "rebuilt over and over, where the launch order taken from the previous build fits); HIP events on the "
                                            "feature map's own stream: one before the build's first kernel and one behind its last; the stage "
                                            f"table comes from {args.single_frames} more frames with an event between the stages, which cost 3 - 5 us "
                                            f"each (their sum: {stage_sum:.4f} ms)",
@@ -386,10 +450,21 @@ def main():
                 "b_ms": b_ms, "s_ms": s_ms_,
                 "strong_speedup_bound": {str(n): (b_ms + s_ms_) / (b_ms + s_ms_ / n) for n in (1, 2, 4, 8)},
                 "weak_speedup_bound": {str(n): float(n) for n in (1, 2, 4, 8)}}
-            out["dt3_build_ms"] = span
+            # BASELINE.json's "DT3 build ms": host preparation (plan, staging, launches) + the kernels' span of a blocking
+            # build of a new scene, as fdcm_featuremap_last_timing reports it; the kernels alone beside it
+            out["dt3_build_ms"] = single["build_total_ms"]
+            out["dt3_build_kernels_ms"] = span
             out["search_kernels_ms"] = single["search_kernel_ms"]
             out["single_frame_ms"] = single["frame_ms"]
             out["single_frame_matches_per_s"] = n_matches / (single["frame_ms"] * 1e-3)
+        if api:
+            out["api_frame_ms"] = api["frame_ms"]
+            out["api_matches_per_s"] = api["matches_per_s"]
+            out["api"] = {"note": "the reference's Python call sequence per blocking frame, through `import openfdcm_amd as openfdcm` only: "
+                                  "build_cpu_featuremap -> search -> get_template_lengths -> penalize(ExponentialPenalty(1.5)) -> sort_matches "
+                                  f"(python/src/matching.cpp:116-130,279-307), {n_scenes} scenes cycled, mean of {api['frames']} frames; compare "
+                                  "with single_frame_ms (rebuild + search through the engine layer, raw records)",
+                          "calls_ms": api["calls_ms"], "iterate_all_matches_ms": api["iterate_all_matches_ms"]}
         if out["dt3_build_ms"] is None:  # --single-frames 0: only the contended span is known
             out["dt3_build_ms"] = avg["total_ms"]
         if args.cpu_sample != 0:
@@ -403,13 +478,13 @@ def main():
                 got = got_all[got_all["tmpl_idx"] < sample]
                 return len(got) == len(want) and got.tobytes() == np.asarray(want, dtype=_capi.MATCH_DTYPE).tobytes()
 
+            from oracle import oracle as O
+            wants = [want0]
             if n_scenes == 1:
                 same, checked = same_as_oracle(gpu_last, want0), 1
                 n_rec = len(want0)
             else:  # every timed frame against the oracle's records of ITS scene
-                from oracle import oracle as O
                 cores = os.cpu_count() or 1
-                wants = [want0]
                 for sc in scenes[1:]:
                     ofm = O.build(sc, depth=cfg["depth"], coeff=5.0, padding=1.0, distance=cfg["distance"], nthreads=cores)
                     wants.append(O.search(ofm, all_templates[:sample], sc, 4, 4, kind=O.BATCH_OPTIMIZE, batch=10, nthreads=cores))
@@ -421,6 +496,23 @@ def main():
                                          f"{'the last timed frame' if n_scenes == 1 else f'all {checked} timed frames ({n_scenes} scenes cycled)'}"
                                          f" ({n_rec} records) against the CPU oracle, bit for bit")
             gate_failed = not same
+            if api:  # the API leg's last frame: the raw list and the penalised, sorted list against the oracle's
+                si, matches, best = api["last"]
+                n_own = min(sample, searcher.end)
+                want = np.asarray(wants[si], dtype=_capi.MATCH_DTYPE)
+                want = want[want["tmpl_idx"] < n_own]
+                got = matches.records()
+                got = got[got["tmpl_idx"] < n_own]
+                lens = np.array([O.eigen_sum(np.array([O.line_props(np.ascontiguousarray(t[:, i]))[1] for i in range(t.shape[1])],
+                                                      dtype=np.float32)) for t in all_templates[:n_own]], dtype=np.float32)
+                want_best = O.sort_matches(O.penalize(want, lens, 1.5))
+                got_best = best.records()
+                ok_api = (got.tobytes() == want.tobytes() and
+                          (n_own < searcher.end or np.ascontiguousarray(got_best).tobytes() == want_best.tobytes()))
+                out["api"]["parity_gate"] = "ok" if ok_api else "FAILED"
+                out["api"]["parity_gate_detail"] = (f"search(): {len(want)} records of the last API frame; sort_matches(penalize()): the same list "
+                                                    "penalised and sorted by the oracle (std::sort, ties included), bit for bit")
+                gate_failed = gate_failed or not ok_api
     pipe.close()
     if use_dist:
         dist.barrier()

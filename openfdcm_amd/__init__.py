@@ -11,6 +11,7 @@ import enum as _enum
 import numpy as _np
 
 from . import _capi
+from .matchlist import Match, MatchList, records_of  # noqa: F401
 from .engine import DeviceFeatureMap, DeviceTemplates, FramePipeline, ShardedEngine, search_raw, topk  # noqa: F401  (extensions)
 
 __version__ = "0.10.0"  # API level of the reference this mirrors (openfdcm.cpp:43)
@@ -63,6 +64,8 @@ class Dt3Cpu:
     constructor (matching.cpp:73): dt3map is {angle: (H, W) array}.
     """
 
+    _pool_key = None  # set by build_cpu_featuremap: where the device handle goes when this object is dropped
+
     def __init__(self, dt3map, scene_translation=(0.0, 0.0), feature_size=(0, 0), _device=None):
         if _device is not None:
             self._fm = _device
@@ -86,6 +89,13 @@ class Dt3Cpu:
 
     def get_dt3_map(self):
         return {float(k): self._fm.slice(i) for i, k in enumerate(self._fm.keys)}
+
+    def __del__(self):
+        try:
+            if self._pool_key is not None and self._fm._h:
+                _featuremap_pool.give(self._pool_key, self._fm)
+        except Exception:  # interpreter shutdown: the handle's own __del__ frees it
+            pass
 
     def __repr__(self):
         t = self._fm.scene_translation
@@ -119,12 +129,64 @@ class FeatureMap:
     def __repr__(self): return "<FeatureMap>"
 
 
+class _FeatureMapPool:
+    """Device feature maps whose `Dt3Cpu` was dropped, kept for the next `build_cpu_featuremap` with the same
+    parameters.  The reference's callers build a new feature map every frame (matching.cpp:116-130: a fresh Dt3Cpu of
+    O(V) host memory each call); here a fresh handle is two volumes of HBM, workspaces and a stream -- allocating and
+    freeing them costs more than the build -- so `fm = build_cpu_featuremap(scene, params)` in a loop alternates
+    between two handles (the old `fm` is dropped after the new one exists) and each call is a rebuild.
+    At most PER_KEY idle handles per parameter set and TOTAL in all; `clear_featuremap_pool()` frees them."""
+    PER_KEY, TOTAL = 2, 4
+
+    def __init__(self):
+        self._idle = {}  # (depth, coeff, padding, distance, device) -> [DeviceFeatureMap]
+
+    def take(self, key):
+        lst = self._idle.get(key)
+        return lst.pop() if lst else None
+
+    def give(self, key, fm):
+        lst = self._idle.setdefault(key, [])
+        if len(lst) >= self.PER_KEY or sum(len(v) for v in self._idle.values()) >= self.TOTAL:
+            fm.close()
+        else:
+            lst.append(fm)
+
+    def clear(self):
+        idle, self._idle = self._idle, {}
+        for lst in idle.values():
+            for fm in lst:
+                fm.close()
+
+
+_featuremap_pool = _FeatureMapPool()
+
+
+def clear_featuremap_pool():
+    """Free the idle device feature maps kept for build_cpu_featuremap (extension)."""
+    _featuremap_pool.clear()
+
+
 def build_cpu_featuremap(scene, params=None, pool=None):
-    """matching.cpp:116-130.  The name is the reference's; the build runs on the GPU."""
+    """matching.cpp:116-130.  The name is the reference's; the build runs on the GPU (queued: the call returns once the
+    kernels are launched, whatever reads the feature map next is ordered behind them)."""
+    import ctypes as C
     params = params if params is not None else Dt3CpuParameters()
-    fm = DeviceFeatureMap.build(scene, depth=params.depth, coeff=params.dt3_coeff, padding=params.padding,
-                                distance=int(params.distance))
-    return Dt3Cpu(None, _device=fm)
+    dev = C.c_int()
+    _capi.check(_capi.lib().fdcm_get_device(C.byref(dev)))
+    key = (int(params.depth), float(params.dt3_coeff), float(params.padding), int(params.distance), dev.value)
+    fm = _featuremap_pool.take(key)
+    if fm is None:
+        fm = DeviceFeatureMap.build(scene, depth=key[0], coeff=key[1], padding=key[2], distance=key[3])
+    else:
+        try:
+            fm.rebuild(scene)
+        except Exception:
+            fm.close()
+            raise
+    out = Dt3Cpu(None, _device=fm)
+    out._pool_key = key
+    return out
 
 
 # ---------------------------------------------------------------- optimise strategies
@@ -239,36 +301,65 @@ class MatchStrategy:
     def __repr__(self): return "<MatchStrategy>"
 
 
-class Match:
-    """matchstrategy.h:35-44; transform is a (2, 3) float32 array."""
-
-    def __init__(self, tmpl_idx, score, transform):
-        self.tmpl_idx = int(tmpl_idx)
-        self.score = float(score)
-        self.transform = _np.asarray(transform, dtype=_np.float32).reshape(2, 3)
-
-    def __repr__(self):
-        return f"<Match tmplIdx={self.tmpl_idx}, score={self.score:g}, transform=\n{self.transform}>"
-
-
 def _unwrap(x, wrapper):
     return x._impl if isinstance(x, wrapper) else x
 
 
-def _matches_to_records(matches):
-    rec = _np.zeros(len(matches), dtype=_capi.MATCH_DTYPE)
-    for i, m in enumerate(matches):
-        rec[i] = (m.tmpl_idx, m.score, _np.asarray(m.transform, dtype=_np.float32).reshape(6))
-    return rec
+class _TemplateCache:
+    """The DeviceTemplates of the template lists `search` / `get_template_lengths` were last called with.  The
+    reference's callers pass the same Python list frame after frame (matching.cpp:279-300 copies it into a std::vector
+    on every call); here that would be a device upload per call.  A hit needs the same list object with the same
+    line counts and the same bytes: the list is packed (one concatenate, ~0.3 ms for 1000 x 32 lines) and compared with
+    what was uploaded, so a template edited in place is seen.  Four lists are remembered; `clear_template_cache()`
+    drops them (each holds its list and a device copy alive)."""
+    SLOTS = 4
+
+    def __init__(self):
+        self._entries = []  # most recent first: (list object, line counts, packed lines, DeviceTemplates)
+
+    def get(self, templates):
+        if isinstance(templates, DeviceTemplates):
+            return templates
+        if not isinstance(templates, (list, tuple)):
+            templates = list(templates)
+        if templates and all(type(t) is _np.ndarray and t.ndim == 2 and t.shape[0] == 4 for t in templates):
+            counts = [t.shape[1] for t in templates]
+            data = _np.concatenate(templates, axis=1)  # (4, sum N_i), the elements' own dtype
+            packed = None
+        else:
+            packed = _capi.pack_templates(templates)
+            counts, data = packed[1].tolist(), packed[0]
+        for k, (obj, ecounts, edata, tset) in enumerate(self._entries):
+            if (obj is templates and tset._h and ecounts == counts and edata.dtype == data.dtype
+                    and edata.shape == data.shape and _np.array_equal(edata, data)):
+                if k:
+                    self._entries.insert(0, self._entries.pop(k))
+                return tset
+        self._entries = [e for e in self._entries if e[0] is not templates]
+        if packed is None:
+            offsets = _np.zeros(len(counts) + 1, dtype=_np.int64)
+            _np.cumsum(counts, out=offsets[1:])
+            packed = (_np.ascontiguousarray(data.T, dtype=_np.float32).reshape(-1, 4), offsets)
+        tset = DeviceTemplates(templates, _packed=packed)
+        self._entries.insert(0, (templates, counts, data, tset))
+        del self._entries[self.SLOTS:]
+        return tset
+
+    def clear(self):
+        self._entries.clear()
 
 
-def _records_to_matches(rec):
-    return [Match(int(r["tmpl_idx"]), float(r["score"]), r["transform"].reshape(2, 3).copy()) for r in rec]
+_template_cache = _TemplateCache()
+
+
+def clear_template_cache():
+    """Forget the template lists uploaded on behalf of search() / get_template_lengths() (extension)."""
+    _template_cache.clear()
 
 
 def search(matcher, searcher, optimizer, featuremap, templates, scene):
-    """matching.cpp:279-289 -> search<DefaultMatch> (defaultmatch.cpp:32-89).  Returns the raw,
-    unsorted list[Match] in the reference's positional order."""
+    """matching.cpp:279-289 -> search<DefaultMatch> (defaultmatch.cpp:32-89).  Returns the raw, unsorted matches in
+    the reference's positional order as a MatchList (matchlist.py: a list[Match] whose elements are made on access)."""
     matcher = _unwrap(matcher, MatchStrategy)
     searcher = _unwrap(searcher, SearchStrategy)
     optimizer = _unwrap(optimizer, OptimizeStrategy)
@@ -302,20 +393,19 @@ def search(matcher, searcher, optimizer, featuremap, templates, scene):
     dt3 = featuremap._dt3 if isinstance(featuremap, FeatureMap) else featuremap
     if not isinstance(dt3, Dt3Cpu):
         raise TypeError("featuremap must be a Dt3Cpu or FeatureMap")
-    tset = templates if isinstance(templates, DeviceTemplates) else DeviceTemplates(list(templates))
+    tset = _template_cache.get(templates)
     rec = search_raw(dt3._fm, tset, scene_for_search, searcher.get_max_tmpl_lines(), searcher.get_max_scene_lines(), kind,
                      batch)
-    return _records_to_matches(rec)
+    return MatchList(rec)
 
 
 def get_template_lengths(templates):
     """core::getTemplateLengths (math.h:319-324)."""
-    tset = templates if isinstance(templates, DeviceTemplates) else DeviceTemplates(list(templates))
-    return [float(v) for v in tset.lengths()]
+    return _template_cache.get(templates).lengths().tolist()
 
 
 def penalize(penalty, matches, templatelengths):
-    """matching.cpp:291-297; returns a new list."""
+    """matching.cpp:291-297; returns a new list (a MatchList; `matches` may be one or any list of Match)."""
     import ctypes as C
     penalty = _unwrap(penalty, PenaltyStrategy)
     if isinstance(penalty, ExponentialPenalty):
@@ -324,21 +414,21 @@ def penalize(penalty, matches, templatelengths):
         kind, tau = _capi.DEFAULT_PENALTY, 1.0
     else:
         raise TypeError("penalty must be DefaultPenalty or ExponentialPenalty")
-    rec = _matches_to_records(matches)
+    rec = records_of(matches)
     lens = _np.ascontiguousarray(templatelengths, dtype=_np.float32)
     rc = _capi.lib().fdcm_penalize(kind, tau, C.c_void_p(rec.ctypes.data), len(rec), _capi.fptr(lens), len(lens))
     if rc == -1 and "templatelengths" in _capi.lib().fdcm_last_error().decode():
         raise IndexError(_capi.lib().fdcm_last_error().decode())  # std::out_of_range -> IndexError
     _capi.check(rc)
-    return _records_to_matches(rec)
+    return MatchList(rec)
 
 
 def sort_matches(matches):
     """matching.cpp:302-307: ascending score (std::sort, unstable on ties)."""
     import ctypes as C
-    rec = _matches_to_records(matches)
+    rec = records_of(matches)
     _capi.check(_capi.lib().fdcm_sort_matches(C.c_void_p(rec.ctypes.data), len(rec)))
-    return _records_to_matches(rec)
+    return MatchList(rec)
 
 
 from .lineio import read, write  # noqa: E402  (.lines/.scene/.tmpl files, serialization.h)

@@ -154,8 +154,16 @@ def as_records(lines):
 
 
 def pack_templates(templates):
+    """list of (4, N_i) LineArrays -> ((sum N_i, 4) float32 records, int64 offsets of length len + 1)."""
+    n = len(templates)
+    offsets = np.zeros(n + 1, dtype=np.int64)
+    if n and all(isinstance(t, np.ndarray) and t.ndim == 2 and t.shape[0] == 4 for t in templates):
+        # the usual case in one concatenate instead of a transpose + copy per template
+        np.cumsum([t.shape[1] for t in templates], out=offsets[1:])
+        if offsets[-1] == 0:
+            return np.zeros((0, 4), dtype=np.float32), offsets
+        return np.ascontiguousarray(np.concatenate(templates, axis=1).T, dtype=np.float32), offsets
     recs = [as_records(t) for t in templates]
-    offsets = np.zeros(len(recs) + 1, dtype=np.int64)
     for i, r in enumerate(recs):
         offsets[i + 1] = offsets[i] + r.shape[0]
     if recs and offsets[-1] > 0:

@@ -161,8 +161,8 @@ class DeviceFeatureMap:
 class DeviceTemplates:
     """Owns an fdcm_templates handle: a list of LineArrays resident in HBM."""
 
-    def __init__(self, templates):
-        flat, offsets = capi.pack_templates(templates)
+    def __init__(self, templates, _packed=None):
+        flat, offsets = _packed if _packed is not None else capi.pack_templates(templates)
         self.count = len(offsets) - 1
         h = C.c_void_p()
         capi.check(capi.lib().fdcm_templates_create(capi.fptr(flat), offsets.ctypes.data_as(C.POINTER(C.c_int64)),

@@ -1034,4 +1034,18 @@ void fdcmo_combine(float tx, float ty, const float* T, float* out6) {
     std::memcpy(out6, c.m, 24);
 }
 float fdcmo_atanf(float x) { return std::atan(x); }
+// sortMatches, matchstrategy.h:46-50: std::sort over the Match structs with operator< on the score.
+void fdcmo_sort_matches(Match* m, long n) {
+    std::sort(m, m + n, [](const Match& a, const Match& b) { return a.score < b.score; });
+}
+// penalize<DefaultPenalty> (defaultpenalty.cpp:33-45) / penalize<ExponentialPenalty> (exponentialpenalty.cpp:33-48);
+// returns -1 where templatelengths.at() throws.
+int fdcmo_penalize(int exponential, float tau, Match* m, long n, const float* lengths, long n_lengths) {
+    for (long i = 0; i < n; ++i) {
+        if (m[i].tmplIdx < 0 || m[i].tmplIdx >= n_lengths) return -1;
+        const float len = std::max(lengths[m[i].tmplIdx], 1e-6f);
+        m[i].score = exponential ? m[i].score / std::pow(len, tau) : m[i].score / len;
+    }
+    return 0;
+}
 }

@@ -86,6 +86,9 @@ def lib():
         _lib.fdcmo_eigen_sum.argtypes = [fp, C.c_long]
         _lib.fdcmo_atanf.restype = C.c_float
         _lib.fdcmo_atanf.argtypes = [C.c_float]
+        _lib.fdcmo_sort_matches.argtypes = [vp, C.c_long]
+        _lib.fdcmo_penalize.restype = C.c_int
+        _lib.fdcmo_penalize.argtypes = [C.c_int, C.c_float, vp, C.c_long, fp, C.c_long]
     return _lib
 
 
@@ -385,3 +388,20 @@ def combine(translation, T):
     f.argtypes = [C.c_float, C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     f(float(translation[0]), float(translation[1]), _fp(t), _fp(out))
     return out.reshape(2, 3)
+
+
+def sort_matches(records):
+    """sortMatches (matchstrategy.h:46-50) on a copy of the MATCH_DTYPE records."""
+    rec = np.array(records, dtype=MATCH_DTYPE, copy=True, order="C")
+    lib().fdcmo_sort_matches(rec.ctypes.data, len(rec))
+    return rec
+
+
+def penalize(records, lengths, tau=None):
+    """penalize<DefaultPenalty> (tau None) / penalize<ExponentialPenalty> on a copy of the records."""
+    rec = np.array(records, dtype=MATCH_DTYPE, copy=True, order="C")
+    lens = np.ascontiguousarray(lengths, dtype=np.float32)
+    rc = lib().fdcmo_penalize(0 if tau is None else 1, 0.0 if tau is None else tau, rec.ctypes.data, len(rec), _fp(lens), len(lens))
+    if rc:
+        raise IndexError("templatelengths is not consistent with match template indices")
+    return rec

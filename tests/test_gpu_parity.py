@@ -390,6 +390,79 @@ def test_config2p_match_list_1000_templates(amd):
     want = O.search(orc, tmpls, scene, 4, 4, kind=O.BATCH_OPTIMIZE, batch=10, nthreads=nt)
     assert len(tmpls) == 1000 and len(want) > 20000
     assert assert_matches_close(got, want, "config 2'"), "not bit-identical"
+    dev.close()
+    # The same frame through the reference's Python names only (matching.cpp:116-130,279-307): the lazy MatchList holds
+    # the same records, the tail equals the oracle's penalize + std::sort (ties included), and the calls cost
+    # milliseconds, not the 0.58 s that a Python object per match cost in round 5.
+    import time
+    openfdcm = amd
+    params = openfdcm.Dt3CpuParameters(depth=c["depth"], dt3Coeff=5.0, padding=1.0, distance=openfdcm.distance(c["distance"]))
+    strategy, optimizer, penalty = openfdcm.DefaultSearch(4, 4), openfdcm.BatchOptimize(10), openfdcm.ExponentialPenalty(1.5)
+    walls = []
+    for i in range(6):
+        t0 = time.perf_counter()
+        featuremap = openfdcm.build_cpu_featuremap(scene, params)
+        matches = openfdcm.search(openfdcm.DefaultMatch(), strategy, optimizer, featuremap, tmpls, scene)
+        lens = openfdcm.get_template_lengths(tmpls)
+        best = openfdcm.sort_matches(openfdcm.penalize(penalty, matches, lens))
+        walls.append(time.perf_counter() - t0)
+    assert isinstance(matches, openfdcm.MatchList) and matches.records().tobytes() == np.asarray(want).tobytes()
+    assert best.records().tobytes() == O.sort_matches(O.penalize(want, np.array(lens, dtype=np.float32), 1.5)).tobytes()
+    assert best[0].score == min(m.score for m in best[:50]) and best[0].transform.shape == (2, 3)
+    t0 = time.perf_counter()
+    n = sum(1 for m in matches if m.tmpl_idx >= 0)
+    t_iter = time.perf_counter() - t0
+    assert n == len(want)
+    assert min(walls[2:]) < 0.010, f"API frame {min(walls[2:]) * 1e3:.2f} ms"
+    assert t_iter < 0.030, f"iterating {n} matches {t_iter * 1e3:.1f} ms"
+    openfdcm.clear_featuremap_pool()
+    openfdcm.clear_template_cache()
+
+
+def test_api_template_cache_and_featuremap_pool(amd):
+    """search() / get_template_lengths() keep the device copy of a template list they have seen (same list object, same
+    bytes) and notice an in-place edit; build_cpu_featuremap() reuses the device handle of a dropped Dt3Cpu."""
+    import openfdcm_amd as api
+    from openfdcm_amd import synthetic
+    S = 200
+    scene, scene2 = synthetic.scene(S, 40, 3), synthetic.scene(S, 50, 4)
+    tmpls = synthetic.templates(20, 10, S, 5)
+    params = api.Dt3CpuParameters(depth=12, dt3Coeff=5.0, padding=1.1)
+    args = (api.DefaultMatch(), api.DefaultSearch(3, 4), api.BatchOptimize(5))
+    api.clear_template_cache()
+    api.clear_featuremap_pool()
+    fm = api.build_cpu_featuremap(scene, params)
+    a = api.search(*args, fm, tmpls, scene)
+    tset = api._template_cache._entries[0][3]
+    b = api.search(*args, fm, tmpls, scene)
+    assert api._template_cache._entries[0][3] is tset and len(api._template_cache._entries) == 1 and a == b
+    assert api.get_template_lengths(tmpls) == api.get_template_lengths([t.copy() for t in tmpls])
+    orc = O.build(scene, depth=12, coeff=5.0, padding=1.1)
+    assert a.records().tobytes() == np.asarray(O.search(orc, tmpls, scene, 3, 4, kind=O.BATCH_OPTIMIZE, batch=5)).tobytes()
+    tmpls[7][:, 2] += 11.0                                     # edited in place: same list, same arrays, other bytes
+    c = api.search(*args, fm, tmpls, scene)
+    assert api._template_cache._entries[0][3] is not tset
+    assert c.records().tobytes() == np.asarray(O.search(orc, tmpls, scene, 3, 4, kind=O.BATCH_OPTIMIZE, batch=5)).tobytes()
+    tmpls.append(tmpls[0].copy())                               # grown
+    d = api.search(*args, fm, tmpls, scene)
+    assert d.records().tobytes() == np.asarray(O.search(orc, tmpls, scene, 3, 4, kind=O.BATCH_OPTIMIZE, batch=5)).tobytes()
+    # the pool: a dropped feature map's handle serves the next build with the same parameters (and only those)
+    h = fm._fm._h.value
+    del fm
+    assert sum(len(v) for v in api._featuremap_pool._idle.values()) == 1
+    other = api.build_cpu_featuremap(scene2, api.Dt3CpuParameters(depth=8, dt3Coeff=5.0, padding=1.1))
+    assert other._fm._h.value != h
+    fm2 = api.build_cpu_featuremap(scene2, params)
+    assert fm2._fm._h.value == h and not api._featuremap_pool._idle[fm2._pool_key]
+    orc2 = O.build(scene2, depth=12, coeff=5.0, padding=1.1)
+    assert_volume_equal(fm2._fm, orc2, "pooled handle, new scene")
+    e = api.search(*args, fm2, tmpls, scene2)
+    assert e.records().tobytes() == np.asarray(O.search(orc2, tmpls, scene2, 3, 4, kind=O.BATCH_OPTIMIZE, batch=5)).tobytes()
+    assert tuple(fm2.get_feature_size()) == (orc2.W, orc2.H) and np.array_equal(fm2.get_scene_translation(), orc2.translation)
+    del fm2, other
+    api.clear_featuremap_pool()
+    api.clear_template_cache()
+    assert not api._featuremap_pool._idle and not api._template_cache._entries
 
 
 @pytest.fixture(scope="module")

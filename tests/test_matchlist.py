@@ -1,0 +1,169 @@
+"""MatchList: the lazy list[Match] that search / penalize / sort_matches return (openfdcm_amd/matchlist.py).
+
+Host only (fdcm_penalize / fdcm_sort_matches are host entry points of the C ABI): list semantics a caller of the
+reference's `list[Match]` relies on (matching.cpp:266-307), and that the fast path stays off the per-record Python
+loop (the round-5 API cost: 161 ms to make 27 025 Match objects, 48 ms to turn them back into records)."""
+import time
+
+import numpy as np
+import pytest
+
+import openfdcm_amd as api
+from openfdcm_amd import _capi
+from openfdcm_amd.matchlist import Match, MatchList, records_of
+
+
+def make_records(n, seed=0):
+    rng = np.random.default_rng(seed)
+    rec = np.zeros(n, dtype=_capi.MATCH_DTYPE)
+    rec["tmpl_idx"] = rng.integers(0, 1000, n)
+    rec["score"] = rng.random(n, dtype=np.float32) * 100
+    rec["transform"] = rng.standard_normal((n, 6)).astype(np.float32)
+    return rec
+
+
+def test_sequence_protocol_and_views():
+    rec = make_records(10)
+    ml = MatchList(rec.copy())
+    assert len(ml) == 10 and isinstance(ml[3], Match)
+    assert ml[3].tmpl_idx == int(rec["tmpl_idx"][3]) and ml[-1].score == float(rec["score"][9])
+    assert ml[3].transform.shape == (2, 3) and ml[3].transform.dtype == np.float32
+    assert np.array_equal(ml[3].transform.reshape(6), rec["transform"][3])
+    assert [m.tmpl_idx for m in ml] == rec["tmpl_idx"].tolist()
+    assert [m.tmpl_idx for m in reversed(ml)] == rec["tmpl_idx"][::-1].tolist()
+    with pytest.raises(IndexError):
+        ml[10]
+    with pytest.raises(IndexError):
+        ml[-11]
+    assert isinstance(ml[2:5], MatchList) and len(ml[2:5]) == 3 and ml[2:5][0] == ml[2]
+    assert len(ml[::2]) == 5 and ml[::2][1] == ml[2] and ml[::-1][0] == ml[9]
+    assert ml[3] in ml and ml.index(ml[4]) == 4 and ml.count(ml[4]) >= 1
+    assert sorted(ml, key=lambda m: m.score)[0].score == float(rec["score"].min())
+    assert min(ml, key=lambda m: m.score).score == float(rec["score"].min())
+    assert ml == list(ml) and ml == MatchList(rec.copy()) and not (ml == MatchList(rec[:9].copy()))
+    assert len(ml + list(ml[:2])) == 12 and len(list(ml[:2]) + ml) == 12
+    assert len(MatchList()) == 0 and list(MatchList()) == [] and MatchList() == []
+    assert "MatchList of 10" in repr(ml) and repr(ml[:1]).startswith("[<Match tmplIdx=")
+
+
+def test_elements_write_through_like_list_elements():
+    ml = MatchList(make_records(6))
+    m = ml[2]
+    m.score = 7.5
+    m.tmpl_idx = 42
+    m.transform[0, 2] += 3.0          # in place, as with a def_readwrite Eigen member
+    assert ml[2].score == 7.5 and ml[2].tmpl_idx == 42 and ml.records()["score"][2] == np.float32(7.5)
+    want = ml[2].transform.copy()
+    ml[2].transform = np.arange(6).reshape(2, 3)
+    assert np.array_equal(ml[2].transform, np.arange(6, dtype=np.float32).reshape(2, 3)) and not np.array_equal(want, ml[2].transform)
+    s = ml[1:4]                       # slices share their elements with the list
+    s[1].score = -1.0
+    assert ml[2].score == -1.0
+    for e in ml:                      # mutation while iterating sticks
+        e.score = e.score * 2
+    assert ml[2].score == -2.0
+
+
+def test_restructuring_turns_into_a_real_list_of_the_same_elements():
+    rec = make_records(8, seed=3)
+    ml = MatchList(rec.copy())
+    kept = ml[5]
+    ml.sort(key=lambda m: m.score)
+    assert [m.score for m in ml] == sorted(rec["score"].astype(float).tolist())
+    kept.score = -5.0                 # the element held before the sort is still the list's element
+    assert ml[0].score == -5.0 or any(m.score == -5.0 for m in ml)
+    ml.reverse()
+    del ml[0]
+    ml.append(Match(77, 0.5, np.eye(2, 3)))
+    ml.insert(0, Match(78, 0.25, np.eye(2, 3)))
+    ml[1] = Match(79, 0.125, np.eye(2, 3))
+    assert len(ml) == 9 and ml[0].tmpl_idx == 78 and ml[1].tmpl_idx == 79 and ml[-1].tmpl_idx == 77
+    assert ml.pop().tmpl_idx == 77 and len(ml) == 8
+    r = records_of(ml)
+    assert r.dtype == _capi.MATCH_DTYPE and r["tmpl_idx"].tolist() == [m.tmpl_idx for m in ml]
+    assert isinstance(ml[1:3], MatchList) and len(ml[1:3]) == 2
+    out = api.sort_matches(ml)        # still accepted by the library calls
+    assert [m.score for m in out] == sorted(m.score for m in ml)
+
+
+def test_standalone_match_and_plain_lists_still_work():
+    ms = [Match(i, s, np.eye(2, 3, dtype=np.float32) * i) for i, s in enumerate([3.0, 0.5, 2.0, 0.25])]
+    assert ms[1].tmpl_idx == 1 and ms[1].score == 0.5 and ms[2].transform[0, 0] == 2.0
+    out = api.sort_matches(ms)
+    assert isinstance(out, MatchList) and [m.tmpl_idx for m in out] == [3, 1, 2, 0]
+    assert [m.tmpl_idx for m in ms] == [0, 1, 2, 3]  # by value, as std::vector<Match> (matching.cpp:302-307)
+    pen = api.penalize(api.DefaultPenalty(), ms, [2.0, 4.0, 8.0, 16.0])
+    assert [m.score for m in pen] == [1.5, 0.125, 0.25, 0.015625] and ms[0].score == 3.0
+    assert Match(1, 2.0, np.eye(2, 3)) == Match(1, 2.0, np.eye(2, 3)) and Match(1, 2.0, np.eye(2, 3)) != Match(1, 2.5, np.eye(2, 3))
+
+    class Duck:                       # anything with the three attributes, as before
+        def __init__(self, i, s): self.tmpl_idx, self.score, self.transform = i, s, [[1, 0, 0], [0, 1, 0]]
+    assert [m.tmpl_idx for m in api.sort_matches([Duck(0, 2.0), Duck(1, 1.0)])] == [1, 0]
+
+
+def test_penalize_and_sort_leave_their_argument_alone():
+    rec = make_records(1000, seed=5)
+    ml = MatchList(rec.copy())
+    lens = np.linspace(1, 50, 1000).astype(np.float32)
+    pen = api.penalize(api.ExponentialPenalty(1.5), ml, lens)
+    srt = api.sort_matches(pen)
+    assert ml.records().tobytes() == rec.tobytes()
+    want = rec.copy()
+    _capi.check(_capi.lib().fdcm_penalize(1, 1.5, want.ctypes.data, len(want), _capi.fptr(lens), len(lens)))
+    assert pen.records().tobytes() == want.tobytes()
+    assert np.all(np.diff(srt.records()["score"]) >= 0) and sorted(srt.records()["tmpl_idx"].tolist()) == sorted(rec["tmpl_idx"].tolist())
+    with pytest.raises(IndexError):
+        api.penalize(api.DefaultPenalty(), ml, lens[:10])
+
+
+def test_fast_path_cost_at_config_2p_size():
+    """27 025 records (config 2'): the README tail (penalize + sort_matches) and a full iteration.  Round 5: 0.58 s."""
+    n = 27025
+    ml = MatchList(make_records(n, seed=9))
+    lens = np.linspace(1, 50, 1000).astype(np.float32)
+    best = (1e9, 1e9)
+    for _ in range(3):
+        t0 = time.perf_counter()
+        out = api.sort_matches(api.penalize(api.ExponentialPenalty(1.5), ml, lens))
+        t1 = time.perf_counter()
+        acc = 0.0
+        for m in out:
+            acc += m.score
+        t2 = time.perf_counter()
+        best = (min(best[0], t1 - t0), min(best[1], t2 - t1))
+    assert len(out) == n and acc > 0
+    assert best[0] < 0.010, f"penalize + sort_matches of {n} records took {best[0] * 1e3:.1f} ms"
+    assert best[1] < 0.030, f"iterating {n} matches took {best[1] * 1e3:.1f} ms"
+
+
+def test_sort_and_penalize_equal_the_reference_order_with_ties():
+    """fdcm_sort_matches must end in the permutation std::sort gives on the reference's Match structs
+    (matchstrategy.h:46-50), ties included; fdcm_penalize computes the divisor once per template."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(11)
+    for n, nd in [(0, 1), (1, 1), (2, 1), (17, 3), (255, 40), (256, 10 ** 9), (256, 5), (5000, 10 ** 9), (5000, 50), (27025, 10 ** 9),
+                  (27025, 3000), (70000, 7)]:
+        rec = make_records(n, seed=n + nd % 97)
+        if nd < 10 ** 9:
+            rec["score"] = rng.integers(-nd, nd, n).astype(np.float32) * np.float32(0.37)   # many equal scores
+        else:
+            rec["score"] = (rng.standard_normal(n) * 10.0 ** rng.integers(-3, 6, n)).astype(np.float32)  # both signs, no ties to speak of
+        if n > 4 and (nd < 10 ** 9 or n == 5000):
+            rec["score"][1] = 0.0
+            rec["score"][3] = -0.0            # equal under operator<, different bits
+        got = records_of(api.sort_matches(MatchList(rec.copy())))
+        assert got.tobytes() == O.sort_matches(rec).tobytes(), (n, nd)
+        lens = (rng.random(1000, dtype=np.float32) * 60).astype(np.float32)
+        lens[::97] = 0.0                      # max(len, 1e-6f)
+        for pen, tau in [(api.DefaultPenalty(), None), (api.ExponentialPenalty(1.5), 1.5), (api.ExponentialPenalty(0.3), np.float32(0.3))]:
+            p = records_of(api.penalize(pen, MatchList(rec.copy()), lens))
+            assert p.tobytes() == O.penalize(rec, lens, tau).tobytes(), (n, nd, tau)
+            p = records_of(api.penalize(pen, MatchList(rec[:300].copy()), lens))   # fewer matches than templates
+            assert p.tobytes() == O.penalize(rec[:300], lens, tau).tobytes()
+    inf = make_records(400, seed=1)
+    inf["score"][::7] = np.inf
+    inf["score"][3::11] = -np.inf
+    assert records_of(api.sort_matches(MatchList(inf.copy()))).tobytes() == O.sort_matches(inf).tobytes()
+    nan = make_records(400, seed=2)
+    nan["score"][5] = np.nan                  # std::sort's answer, whatever it is
+    assert records_of(api.sort_matches(MatchList(nan.copy()))).tobytes() == O.sort_matches(nan).tobytes()
