@@ -75,7 +75,10 @@ typedef struct fdcm_build_timing {
 
 typedef struct fdcm_search_timing {
     float total_ms;  /* the search's span on the device: kernels + download of the matches */
-    float kernel_ms; /* candidate generation + optimisation + compaction on the device */
+    float kernel_ms; /* candidate generation + optimisation + compaction on the device, from the event that precedes them on the
+                      * handle's stream.  A handle that has the GPU to itself runs the search's preparation (scene upload,
+                      * candidate pairs, work list) on a second stream beside a build that is still running: the part of it
+                      * that overlaps the build is then not inside kernel_ms / total_ms */
     int64_t candidates;
     int64_t evaluations; /* translations scored by the reference rule (kept + rejected batches) */
 } fdcm_search_timing;
@@ -300,6 +303,11 @@ int fdcm_orientation_bins_mode(void);
  * the kernel calls the same function).  FDCM_SWEEP_MINCOLS=1..64, the tests' switch, lowers the columns a range holds at
  * least from 16, so that small test images exercise all 8 ranges: this call lets a test see that the switch took. */
 int fdcm_selftest_sweep_ranges(int n_seeded_columns);
+/* Builds of this process whose L2 / L2^2 sweep took its workgroup launch order from the per-chunk times of the handle's
+ * previous build (`from_history`) / from the host's proxy, i.e. a handle's first build of a shape (`from_proxy`); builds
+ * small enough to be resident at once take no order and count in neither.  Lets a test see that a frame slot whose buffers
+ * are reserved before every frame (fdcm_sharded_submit) keeps its history. */
+int fdcm_selftest_sweep_order_counts(int64_t* from_history, int64_t* from_proxy);
 
 #ifdef __cplusplus
 }

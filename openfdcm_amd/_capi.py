@@ -104,6 +104,7 @@ SYMBOLS = [
     ("fdcm_selftest_atanf", C.c_int64, [C.c_uint32, C.c_uint32, C.c_uint64]),
     ("fdcm_orientation_bins_mode", C.c_int, []),
     ("fdcm_selftest_sweep_ranges", C.c_int, [C.c_int]),
+    ("fdcm_selftest_sweep_order_counts", C.c_int, [_i64p, _i64p]),
 ]
 
 _lib = None

@@ -16,6 +16,7 @@
 //                       units; shallow and steep sweeps (the latter through LDS tiles) in one launch  read V, write V
 // Compiled with -ffp-contract=off; divide and sqrt are the correctly rounded forms.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -639,6 +640,13 @@ static void ensure_timing(fdcm_featuremap* fm) {
     fm->timing.created = true;
 }
 
+// builds of this process whose L2 sweep took its launch order from the handle's previous build / from the host's proxy
+static std::atomic<int64_t> g_order_from_history{0}, g_order_from_proxy{0};
+void sweep_order_counts(int64_t* from_history, int64_t* from_proxy) {
+    *from_history = g_order_from_history.load();
+    *from_proxy = g_order_from_proxy.load();
+}
+
 void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after, bool reserve_only) {
     const auto t0 = std::chrono::steady_clock::now();
     FDCM_HIP(hipSetDevice(fm->device));
@@ -646,7 +654,15 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after, bool 
     ensure_timing(fm);
     finish_build(fm);  // the previous build's staging and events are reused below
     hipStream_t st = fm->stream;
-    if (!reserve_only) {  // (a reservation leaves the handle's geometry and content as they are)
+    // A reservation only grows buffers: the handle's geometry, the plan offsets of its last build and the sweep's cost
+    // history stay as they are (restored where the function returns early for it); its content survives unless a volume
+    // buffer had to grow, and the cost history unless the scratch that holds it did.
+    const long kept_cost_chunks = fm->k2_cost_chunks;
+    const int kept_cost_w = fm->k2_cost_w;
+    const void* const kept_stack = fm->stack.p;
+    const bool kept_v1 = fm->vol1_interleaved;
+    const size_t kept_off[6] = {fm->off_raster, fm->off_prop, fm->off_integral, fm->off_keys, fm->off_slice, fm->off_cost};
+    if (!reserve_only) {
         fm->W = plan.W; fm->H = plan.H; fm->m = plan.m; fm->tx = plan.tx; fm->ty = plan.ty;
         fm->keys = plan.keys;
         fm->last_build = fdcm_build_timing{};
@@ -724,9 +740,14 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after, bool 
     fm->stage.reserve(blob);
     fm->plan.reserve(blob);
     if (reserve_only) {  // every buffer a build of this plan's shape takes is in place; nothing was queued
-        fm->k2_cost_chunks = 0;  // (the sweep's cost table of this shape holds nothing yet)
+        fm->off_raster = kept_off[0]; fm->off_prop = kept_off[1]; fm->off_integral = kept_off[2];
+        fm->off_keys = kept_off[3]; fm->off_slice = kept_off[4]; fm->off_cost = kept_off[5];
+        fm->vol1_interleaved = kept_v1;
+        if (fm->stack.p == kept_stack) { fm->k2_cost_chunks = kept_cost_chunks; fm->k2_cost_w = kept_cost_w; }
+        else fm->k2_cost_chunks = 0;  // (a new scratch: its cost table holds nothing yet)
         return;
     }
+    if (sb.order) (proxy_order ? g_order_from_proxy : g_order_from_history).fetch_add(1, std::memory_order_relaxed);
     char* hs = (char*)fm->stage.p;
     if (!plan.raster.empty()) std::memcpy(hs + fm->off_raster, plan.raster.data(), plan.raster.size() * sizeof(RasterLine));
     std::memcpy(hs + fm->off_prop, plan.prop.data(), plan.prop.size() * sizeof(PropStep));

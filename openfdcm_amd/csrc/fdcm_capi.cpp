@@ -586,6 +586,12 @@ int64_t fdcm_selftest_atanf(uint32_t first, uint32_t stride, uint64_t count) {
 }
 
 int fdcm_orientation_bins_mode(void) { return fdcm::orientation_bins_on_host() ? 1 : 0; }
+int fdcm_selftest_sweep_order_counts(int64_t* from_history, int64_t* from_proxy) {
+    return guarded([&] {
+        require(from_history && from_proxy, "null argument");
+        fdcm::sweep_order_counts(from_history, from_proxy);
+    });
+}
 int fdcm_selftest_sweep_ranges(int n_seeded_columns) { return fdcm::sweep_ranges(n_seeded_columns, fdcm::sweep_min_cols()); }
 
 }  // extern "C"

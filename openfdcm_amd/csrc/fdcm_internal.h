@@ -187,11 +187,13 @@ struct fdcm_templates {
 
 namespace fdcm {
 // implemented in fdcm_build.hip
-// reserve_only: size every buffer a build of this plan takes and queue nothing (the handle keeps its geometry and content)
+// reserve_only: size every buffer a build of this plan takes and queue nothing (the handle keeps its geometry, its plan
+// offsets and the sweep's cost history; its content too unless a volume buffer had to grow)
 void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after, bool reserve_only = false);
 // Waits for a queued build (if any) and fills fm->last_build.  run_build only queues the kernels: the search
 // that follows is ordered behind them on the same stream and its host-side preparation runs meanwhile.
 void finish_build(fdcm_featuremap* fm);
+void sweep_order_counts(int64_t* from_history, int64_t* from_proxy);
 // implemented in fdcm_search.hip
 int64_t search_capacity(const fdcm_templates* t, int64_t n_scene, int64_t maxT, int64_t maxS);
 void run_search(fdcm_featuremap* fm, const fdcm_templates* t, const float* scene, int64_t n_scene, int64_t maxT,

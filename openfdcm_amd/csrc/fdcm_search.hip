@@ -721,6 +721,16 @@ void run_search(fdcm_featuremap* fm, const fdcm_templates* t, const float* scene
     const long long ncand = coff[t->T];
     fm->last_search.candidates = ncand;
     if (ncand == 0) return;
+    // ---- every check that can refuse the search, before the first command is queued (a refusal must not leave an upload
+    // in flight on the preparation stream that the next call's staging would overwrite)
+    if (fm->vol_stage != 3) throw std::string("the feature map holds a partial build (no line integral): nothing to search");
+    const int64_t B = optimizer == FDCM_BATCH_OPTIMIZE ? std::max<int64_t>(1, batch) : 1;
+    if (B > 4096) throw std::string("batch_size above 4096 is not supported");
+    const int win = B <= 15 ? (int)((15 / B) * B) : (int)B;  // multipliers scored per direction and round: whole batches, 15 at most when they fit one round
+    const int lds_lines = (int)std::max<int64_t>(1, t->max_lines);
+    const size_t lds = (size_t)kWavesPerBlock * ((size_t)fm->m + 5 * (size_t)lds_lines + 2 * (size_t)win + 1) * sizeof(float);
+    if (lds > 160 * 1024) throw std::string("scene/template too large for the search kernel's LDS staging");
+    if (host_bins_needed && fm->m > 65535) throw std::string("host-side orientation bins need depth <= 65535");
     // ---- stage + upload: scene lines | sorted lengths | sorted idx | candidate offsets
     auto align16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
     const size_t o_lines = 0, o_len = align16((size_t)n_s * 16), o_idx = o_len + align16((size_t)n_s * 4),
@@ -752,7 +762,6 @@ void run_search(fdcm_featuremap* fm, const fdcm_templates* t, const float* scene
     fm->s_counter.reserve(64);
     // keys live at the end of the build plan blob; for adopted volumes they are uploaded there too
     SearchParams P{};
-    if (fm->vol_stage != 3) throw std::string("the feature map holds a partial build (no line integral): nothing to search");
     P.vol = fm->vol.as<float>();
     P.keys = (const float*)((const char*)fm->plan.p + fm->off_keys);
     P.W = (int)fm->W; P.H = (int)fm->H; P.m = (int)fm->m; P.tx = fm->tx; P.ty = fm->ty;
@@ -768,18 +777,15 @@ void run_search(fdcm_featuremap* fm, const fdcm_templates* t, const float* scene
     P.n_s = n_s;
     P.maxT = (int)maxT; P.maxS = (int)maxS; P.window = window;
     P.optimizer = optimizer;
-    const int64_t B = optimizer == FDCM_BATCH_OPTIMIZE ? std::max<int64_t>(1, batch) : 1;
-    if (B > 4096) throw std::string("batch_size above 4096 is not supported");
     P.batch = (int)B;
-    // multipliers scored per direction and round: whole batches, 15 at most when they fit one round
-    P.win = B <= 15 ? (int)((15 / B) * B) : (int)B;
+    P.win = win;
     P.base = base;
     P.cand_offsets = (const long long*)(ds + o_coff);
     P.bpt = (int)((cpt_max + kWavesPerBlock - 1) / kWavesPerBlock);
     P.ncand = ncand;
     static const int env_xcd_parts = getenv("FDCM_SEARCH_XCD_PARTS") ? atoi(getenv("FDCM_SEARCH_XCD_PARTS")) : 0;  // tuning override, read once
     P.xcd_parts = env_xcd_parts;
-    P.lds_lines = (int)std::max<int64_t>(1, t->max_lines);
+    P.lds_lines = lds_lines;
     P.records = fm->s_records.as<fdcm_match>();
     P.flags = fm->s_flags.as<int>();
     P.evals = P.flags + ncand + nchunks;
@@ -787,9 +793,6 @@ void run_search(fdcm_featuremap* fm, const fdcm_templates* t, const float* scene
     P.pairs_stride = (int)(maxT * window);
     fm->s_pairs.reserve(std::max<size_t>(16, (size_t)t->T * P.pairs_stride * sizeof(int2)));
     P.pairs = fm->s_pairs.as<int2>();
-    const size_t lds_floats = (size_t)kWavesPerBlock * ((size_t)P.m + 5 * (size_t)P.lds_lines + 2 * P.win + 1);
-    const size_t lds = lds_floats * sizeof(float);
-    if (lds > 160 * 1024) throw std::string("scene/template too large for the search kernel's LDS staging");
     // volumes below 4 GB (every BASELINE config but 5) are addressed through one buffer descriptor with 32-bit offsets
     static const bool env_flat = getenv("FDCM_SEARCH_FLAT") != nullptr;  // measurement: 64-bit flat addresses always
     const bool buf32 = !env_flat && (size_t)fm->m * ivol_slice_floats(fm->W, fm->H) * sizeof(float) < ((size_t)1 << 32);
@@ -827,7 +830,6 @@ void run_search(fdcm_featuremap* fm, const fdcm_templates* t, const float* scene
         FDCM_HIP(hipStreamWaitEvent(st, fm->prep_done, 0));
     }
     if (host_bins_needed) {
-        if (fm->m > 65535) throw std::string("host-side orientation bins need depth <= 65535");
         const size_t stride = (size_t)P.lds_lines;
         fm->s_bins_stage.reserve((size_t)ncand * stride * sizeof(unsigned short));
         fm->s_bins.reserve((size_t)ncand * stride * sizeof(unsigned short));

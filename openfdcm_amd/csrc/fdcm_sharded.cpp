@@ -298,6 +298,8 @@ int64_t submit_frame(fdcm_sharded* s, Job&& job) {
             run_build(fs.fm, plan, 3, /*reserve_only=*/true);
             reserve_search(fs.fm, sh.tset, job.n_scene, job.maxT, job.maxS);
         } catch (const std::string&) {  // e.g. a feature size the build rejects: the frame reports it
+        } catch (const HipError&) {     // an allocation that failed: the frame's own build asks again and reports it
+            (void)hipGetLastError();
         }
     }
     for (auto& sh : s->shards) {

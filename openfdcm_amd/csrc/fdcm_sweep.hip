@@ -181,7 +181,9 @@ __device__ __forceinline__ void local_run(const uint4* __restrict__ dp, int W, c
                 const int pc = (int)dq.z, nc = (int)dq.w;
                 const float qf = (float)q;
                 u32x4 dqn = dq;
-                if (mk) {  // the next column's descriptor: in flight until the pop loop's waits
+                if (mk) {  // the next column's descriptor: in flight until the pop loop's waits.  The compiler does not know that:
+                           // dqn is not named again before the `+s` statement behind the loop, and tools/check_sweep_prefetch.py
+                           // (tests/test_capi_load.py) reads the built code to see that nothing touches its SGPRs before that wait
                     q = wd * 64 + __ffsll((long long)mk) - 1;
                     mk &= mk - 1ull;
                     advance();

@@ -88,6 +88,18 @@ def test_sweep_mincols_switch_takes(capi):
         assert out.returncode == 0 and out.stdout.split("\n")[0].strip() == want, (val, out.stdout, out.stderr[-500:])
 
 
+def test_sweep_descriptor_prefetch_is_untouched_until_its_wait():
+    """local_run (csrc/fdcm_sweep.hip) issues the next column's s_load_dwordx4 from inline assembly without a
+    wait; the compiler does not know the SGPRs are in flight.  tools/check_sweep_prefetch.py reads the built library's
+    gfx950 code: nothing names those registers before an s_waitcnt that covers lgkmcnt(0)."""
+    import subprocess
+    import sys
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        pytest.skip("no llvm-objdump")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_sweep_prefetch.py")], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "sweep prefetch check ok" in out.stdout and "k_sweep_balanced" in out.stdout, out.stdout + out.stderr[-1000:]
+
+
 def test_lineio_roundtrip_and_assets(tmp_path):
     from openfdcm_amd import lineio
     from helpers import create_lines

@@ -779,6 +779,19 @@ def test_sharded_engine_frames_in_flight(amd):
     eng.close()
 
 
+def test_sharded_engine_slot_keeps_sweep_history_and_survives_a_failed_first_frame(amd):
+    """fdcm_sharded_submit reserves the slot's buffers before every frame; the reservation must not wipe the L2
+    sweep's per-chunk cost history (one launch order from the host proxy, then the previous build's), and a slot whose
+    first frame cannot be built serves the next (tools/sharded_history.py, FDCM_SWEEP_ORDER=1 in a process of its own)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "sharded_history.py")], capture_output=True, text=True,
+                         timeout=600, env={**os.environ, "FDCM_SWEEP_ORDER": "1"})
+    assert out.returncode == 0 and "sharded history ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
 def test_sharded_engine_leaves_the_callers_device_alone(amd):
     """fdcm_sharded_* switch devices on the caller's thread for allocations and the exchange; the library's
     thread-local device and HIP's current device are what they were when a call returns."""
