@@ -180,6 +180,30 @@ def test_search_edge_cases(amd):
     assert np.array_equal(got["score"][ok].view(np.uint32), want["score"][ok].view(np.uint32))
 
 
+def test_refused_search_leaves_nothing_in_flight(amd):
+    """a search the library refuses (batch above 4096, a partial build) throws before anything is queued on the
+    preparation stream; the next search on the same handle -- whose staging buffer it rewrites -- is the oracle's."""
+    from openfdcm_amd import synthetic, _capi
+    from openfdcm_amd.engine import DeviceFeatureMap, DeviceTemplates, search_raw
+    scene, scene2 = synthetic.scene(256, 50, 8), synthetic.scene(256, 70, 9)
+    tmpls = synthetic.templates(30, 12, 256, 10)
+    tset = DeviceTemplates(tmpls)
+    dev = DeviceFeatureMap.build(scene, depth=16, coeff=5.0, padding=1.0, distance=O.L2)
+    orc = O.build(scene, depth=16, coeff=5.0, padding=1.0, distance=O.L2, nthreads=4)
+    for _ in range(3):
+        with pytest.raises(_capi.FdcmError, match="4096"):
+            search_raw(dev, tset, scene2, 4, 4, O.BATCH_OPTIMIZE, 5000)
+        got = search_raw(dev, tset, scene, 4, 4, O.BATCH_OPTIMIZE, 10)
+        want = O.search(orc, tmpls, scene, 4, 4, kind=O.BATCH_OPTIMIZE, batch=10, nthreads=4)
+        assert assert_matches_close(got, want, "after a refused search"), "not bit-identical"
+    part = DeviceFeatureMap.build(scene, depth=16, coeff=5.0, padding=1.0, distance=O.L2, stop_after=2)
+    with pytest.raises(_capi.FdcmError, match="partial build"):
+        search_raw(part, tset, scene, 4, 4, O.BATCH_OPTIMIZE, 10)
+    part.rebuild(scene)
+    got = search_raw(part, tset, scene, 4, 4, O.BATCH_OPTIMIZE, 10)
+    assert assert_matches_close(got, want, "the partial handle, rebuilt"), "not bit-identical"
+
+
 def test_api_end_to_end_like_reference(amd):
     """tests/python/test_matching.py:45-104 of the reference, through the mirrored API."""
     openfdcm = amd
