@@ -54,7 +54,10 @@ static constexpr int kLabWin = 0;
 #endif
 
 // The LDS ring of stack entries, three planes of consecutive dwords: entry i of workgroup lane c is
-// (2 v, P = f + v^2, z) = plane[0..2][i & (kRing - 1)][c].  (Lanes read and write one plane at a time with 4-byte stride: no bank conflicts.)
+// (2 v, P = f + v^2, z) = plane[0..2][i & (kRing - 1)][c].  In the local run a lane reads and writes its own column c (bank = c mod 32
+// whatever i is: conflict-free, which is what the layout is for).  The merge and the walk read 8 consecutive entries of ONE row
+// with 8 lanes: strides of kNT = 512 dwords, all on one bank (8-way conflicts; 3 % of the kernel's wave cycles -- a stride of
+// 516 would clear them and put lanes of the pop loop that stand at different depths on one bank instead: profiles/NOTES.md section 12).
 struct Ring {
     float* p;
     static constexpr int kPlane = kRing * kNT;  // floats per plane
