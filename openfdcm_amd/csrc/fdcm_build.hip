@@ -624,6 +624,16 @@ __global__ void __launch_bounds__(256) k_integral(const float* __restrict__ src,
     // tiles against straight 1 KB streams), so mixing them over the launch overlaps them.
     const int k = (int)(((long)blockIdx.y * kstride) % (long)gridDim.y);
     const IntegralDesc d = desc[k];
+#ifdef FDCM_LAB
+    // lab builds, FDCM_INT_ONLY=shallow|steep: only that class of slices runs (PMC traffic per class: tools/int_split.sh);
+    // the flag rides in kstride's upper bits
+    const int only = kstride >> 24;
+    kstride &= 0xffffff;
+    const int k2 = (int)(((long)blockIdx.y * kstride) % (long)gridDim.y);
+    const IntegralDesc d2 = desc[k2];
+    if (only && d2.mode != only) return;
+    if (only) { if (d2.mode == 1) integral_shallow(src, dst, W, H, d2, k2, tab, shw); else integral_steep<XC>(src, dst, W, H, d2, k2, lds_tiles); return; }
+#endif
     if (d.mode == 1) integral_shallow(src, dst, W, H, d, k, tab, shw);
     else if (d.mode == 2) integral_steep<XC>(src, dst, W, H, d, k, lds_tiles);
     else {  // nothing to integrate (imgproc.h:43): the slice moves as it is
@@ -867,6 +877,10 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after, bool 
             kstride = m / 2 + 1;
             while (gcd(kstride, m) != 1) ++kstride;
         }
+#ifdef FDCM_LAB
+        static const int env_int_only = [] { const char* e = getenv("FDCM_INT_ONLY"); return !e ? 0 : (!std::strcmp(e, "shallow") ? 1 : (!std::strcmp(e, "steep") ? 2 : 0)); }();
+        kstride |= env_int_only << 24;
+#endif
 #define FDCM_INTEGRAL(XC)                                                                                                        \
         do {                                                                                                                     \
             constexpr size_t lds = integral_lds_bytes<XC>();                                                                     \
