@@ -153,9 +153,11 @@ def main():
     ap.add_argument("--templates", type=int, default=None, help="templates per GPU (default: the config's)")
     ap.add_argument("--cpu-sample", type=int, default=-1,
                     help="templates in the CPU baseline / parity gate (default -1 = all of the rank's; 0 = skip both)")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong", "frames"],
                     help="weak: the config's per-GPU template count on every rank; strong: the config's TOTAL template count "
-                         "(BASELINE.md section 5: 1/2/4/8 GPUs on config 2' itself) cut into N shards")
+                         "(BASELINE.md section 5: 1/2/4/8 GPUs on config 2' itself) cut into N shards; frames: every rank holds the "
+                         "config's whole template list and takes every N-th frame of the stream, no collective on the data path "
+                         "(a step = one frame per rank; the JSON says scaling weak: per-GPU work is fixed)")
     ap.add_argument("--scenes", type=int, default=4,
                     help="distinct scenes cycled through the frames, in the timed region and in the blocking frames the roofline "
                          "is measured on (seeds 1..n; default 4: a caller builds a new scene every frame, matching.cpp:116-130).  "
@@ -174,7 +176,7 @@ def main():
     import torch.distributed as dist
     from openfdcm_amd import synthetic
     from openfdcm_amd import _capi
-    from openfdcm_amd.dist import ShardedPipeline, ShardedSearcher
+    from openfdcm_amd.dist import FrameShards, ShardedPipeline, ShardedSearcher
     from openfdcm_amd.engine import DeviceFeatureMap, search_raw
 
     rank = int(os.environ.get("RANK", "0"))
@@ -198,16 +200,19 @@ def main():
     scene = scenes[0]
     # weak scaling: every rank owns `per_gpu` templates of a global list of world * per_gpu;
     # strong scaling: the global list is the config's own (per_gpu templates in all), cut into `world` contiguous shards
+    by_frames = args.scaling == "frames"
+    fshards = FrameShards(rank, world)
     total_templates = per_gpu * world if args.scaling == "weak" else per_gpu
     all_templates = synthetic.templates(total_templates, cfg["n"], cfg["S"], 2)
-    searcher = ShardedSearcher(all_templates, rank, world, device)
+    # template shards: rank r of `world`; frame shards: every rank is "rank 0 of 1" (the whole list, no gather)
+    searcher = ShardedSearcher(all_templates, 0 if by_frames else rank, 1 if by_frames else world, device)
     recs = [_capi.as_records(sc) for sc in scenes]
     rec = recs[0]
     frame_no = [0]        # frames submitted so far (selects the scene)
     kept = []             # (scene index, matches) of every timed frame when several scenes are cycled
     F = max(1, args.frames)
     pipe = ShardedPipeline.create(searcher, rec.shape[0], cfg["depth"], 5.0, 1.0, cfg["distance"], 4, 4,
-                                  _capi.BATCH_OPTIMIZE, 10, slots=F, gather=use_dist)
+                                  _capi.BATCH_OPTIMIZE, 10, slots=F, gather=use_dist and not by_frames)
     stage_keys = ("seeds_ms", "pass1_ms", "pass2_ms", "propagate_ms", "integral_ms", "total_ms")
     stage_ms = {k: 0.0 for k in stage_keys}
     acc = {"search_kernel_ms": 0.0, "search_total_ms": 0.0, "frames": 0, "n_matches": 0, "evaluations": 0, "last": None}
@@ -219,7 +224,8 @@ def main():
             if len(pipe.pending) == F:
                 collect(record)
             submit_t.append(time.perf_counter())
-            scene_q.append(frame_no[0] % n_scenes)
+            # (frame shards: this rank's frames are rank, rank + N, ... of the stream)
+            scene_q.append((fshards.frame_of(frame_no[0]) if by_frames else frame_no[0]) % n_scenes)
             pipe.submit(recs[scene_q[-1]])
             frame_no[0] += 1
         while pipe.pending:
@@ -231,7 +237,7 @@ def main():
         res = pipe.collect()
         t_sub = submit_t.pop(0)
         si = scene_q.pop(0)
-        if record and n_scenes > 1 and res is not None:
+        if record and (n_scenes > 1 or by_frames) and res is not None:
             kept.append((si, res))
         if record:
             latency.append(time.perf_counter() - t_sub)
@@ -275,7 +281,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     total_matches = acc["n_matches"]            # of all K timed frames (they differ when scenes are cycled)
-    n_matches = total_matches / max(1, args.steps)
+    frame_digests = None
+    if by_frames and use_dist:
+        # every rank delivered its own frames: the job's matches are the sum, and rank 0 gets every frame's digest for the gate
+        total_matches = fshards.total(total_matches, device)
+        sample_n = total_templates if args.cpu_sample < 0 else min(args.cpu_sample, total_templates)
+        frame_digests = fshards.gather_digests(kept, below_template=sample_n)
+    n_matches = total_matches / max(1, args.steps * (world if by_frames else 1))
     gpu_last = None if acc["last"] is None else np.array(acc["last"], copy=True)
 
     # untimed extra: blocking frames (one in flight, the GPU to itself) for the roofline objects.  The frames cycle the
@@ -377,16 +389,20 @@ def main():
         out = {
             "metric": "template matches/sec (DT3 build + DefaultMatch/BatchOptimize search per frame)",
             "value": total_matches / elapsed, "unit": "matches/s", "n_gpus": world, "steps": K,
-            "warmup": args.warmup, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": args.scaling,
+            "warmup": args.warmup, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
+            "scaling": "weak" if by_frames else args.scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"BASELINE config {args.config.replace('p', chr(39))}: {cfg['S']}x{cfg['S']} scene, "
                                    f"{cfg['scene_lines']} lines, depth {cfg['depth']}, {dname}, " +
                                    (f"{per_gpu} templates x {cfg['n']} lines per GPU" if args.scaling == "weak" else
+                                    f"{per_gpu} templates x {cfg['n']} lines on every GPU, {world} frame(s) per step (one per GPU)" if by_frames else
                                     f"{per_gpu} templates x {cfg['n']} lines in all, cut into {world} shard(s)") +
                                    ", DefaultSearch(4,4), BatchOptimize(10)",
                        "templates_total": total_templates, "matches_per_step": n_matches, "frames_in_flight": F,
                        "distinct_scenes": n_scenes,
-                       "parallelism": f"template shards x{world}, DT3 replicated, 1 RCCL gather per frame",
+                       "sharding": "frames" if by_frames else "templates",
+                       "parallelism": (f"frames round-robin over {world} GPU(s), the whole template list on each, no collective on the data path"
+                                       if by_frames else f"template shards x{world}, DT3 replicated, 1 RCCL gather per frame"),
                        "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                        "orientation_bins": "host libm" if _capi.lib().fdcm_orientation_bins_mode() else "device atanf"},
             "frame_latency_ms": {"p50": float(np.percentile(lat, 50)), "p95": float(np.percentile(lat, 95)),
@@ -395,7 +411,7 @@ def main():
                                  # normal spans, a stalled GPU a long one)
                                  "slowest": (lambda i: {"frame": int(i), "latency": frame_log[i][0], "build_span": frame_log[i][1],
                                                         "search_span": frame_log[i][2], "search_kernels": frame_log[i][3]})(int(np.argmax(lat)))},
-            "templates_per_s": total_templates * K / elapsed,
+            "templates_per_s": total_templates * K * (world if by_frames else 1) / elapsed,
             # BASELINE.json's "DT3 build ms": one blocking build with the GPU to itself, host preparation included (set below from
             # the blocking frames; the span of a build inside the timed region, where F frames share the CUs, is
             # in_timed_region.dt3_build_span_ms)
@@ -449,7 +465,11 @@ def main():
                         "32-byte-record gather per frame is the only shared step)",
                 "b_ms": b_ms, "s_ms": s_ms_,
                 "strong_speedup_bound": {str(n): (b_ms + s_ms_) / (b_ms + s_ms_ / n) for n in (1, 2, 4, 8)},
-                "weak_speedup_bound": {str(n): float(n) for n in (1, 2, 4, 8)}}
+                "weak_speedup_bound": {str(n): float(n) for n in (1, 2, 4, 8)},
+                # --scaling frames / fdcm_sharded_set_mode(FDCM_SHARD_FRAMES): a stream of frames dealt round-robin, every GPU the whole
+                # job of its frames, nothing shared: N x the one-GPU rate on the config's own template count (where template
+                # shards are bounded by the replicated build)
+                "frames": {str(n): float(n) for n in (1, 2, 4, 8)}}
             # BASELINE.json's "DT3 build ms": host preparation (plan, staging, launches) + the kernels' span of a blocking
             # build of a new scene, as fdcm_featuremap_last_timing reports it; the kernels alone beside it
             out["dt3_build_ms"] = single["build_total_ms"]
@@ -480,7 +500,7 @@ def main():
 
             from oracle import oracle as O
             wants = [want0]
-            if n_scenes == 1:
+            if n_scenes == 1 and not by_frames:
                 same, checked = same_as_oracle(gpu_last, want0), 1
                 n_rec = len(want0)
             else:  # every timed frame against the oracle's records of ITS scene
@@ -490,10 +510,16 @@ def main():
                     wants.append(O.search(ofm, all_templates[:sample], sc, 4, 4, kind=O.BATCH_OPTIMIZE, batch=10, nthreads=cores))
                 same = len(kept) == K and all(same_as_oracle(np.asarray(res), wants[si]) for si, res in kept)
                 checked, n_rec = len(kept), sum(len(wants[si]) for si, _ in kept)
+                if frame_digests is not None:  # frame shards: every frame of every rank, by digest (rank 0's own were compared above)
+                    want_dig = [FrameShards.digest(np.asarray(w, dtype=_capi.MATCH_DTYPE)) for w in wants]
+                    for r, frames in enumerate(frame_digests):
+                        same = same and len(frames) == K and all((n, h) == want_dig[si] for si, n, h in frames)
+                    checked, n_rec = sum(len(f) for f in frame_digests), sum(n for f in frame_digests for _, n, _ in f)
             out["parity_gate"] = "ok" if same else "FAILED"
-            out["parity_gate_detail"] = (("the gathered list of all ranks: " if world > 1 else "") +
+            out["parity_gate_detail"] = (("every rank's own frames (digests gathered to rank 0): " if frame_digests is not None else
+                                          "the gathered list of all ranks: " if world > 1 else "") +
                                          f"match records of the first {sample} templates of "
-                                         f"{'the last timed frame' if n_scenes == 1 else f'all {checked} timed frames ({n_scenes} scenes cycled)'}"
+                                         f"{'the last timed frame' if n_scenes == 1 and not by_frames else f'all {checked} timed frames ({n_scenes} scenes cycled)'}"
                                          f" ({n_rec} records) against the CPU oracle, bit for bit")
             gate_failed = not same
             if api:  # the API leg's last frame: the raw list and the penalised, sorted list against the oracle's

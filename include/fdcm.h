@@ -220,6 +220,16 @@ int fdcm_sharded_search_topk(fdcm_sharded* s, const float* scene_lines, int64_t 
  * after it.  fdcm_sharded_search / _search_topk are submit + wait.  One caller thread at a time per engine; n_frames
  * is 1 after create and may be changed (1..16) while no frame is in flight. */
 int fdcm_sharded_set_frames_in_flight(fdcm_sharded* s, int n_frames);
+/* What the devices share out.  FDCM_SHARD_TEMPLATES (the default): every frame runs on every device,
+ * each over its contiguous template range, one exchange per frame -- the way to shorten ONE frame, bounded by the build that
+ * every device repeats.  FDCM_SHARD_FRAMES: ticket t runs WHOLE on device t % n_devices over the whole template list (uploaded
+ * to every device by this call), slot (t / n_devices) % n_frames there; no exchange at all, results exactly those of
+ * fdcm_search / fdcm_topk on one device -- the way to raise the throughput of a STREAM of frames (n_devices * n_frames tickets may be
+ * outstanding; wait for them in any order, in submission order to keep every device busy).  Only while no frame is in
+ * flight; tickets restart at 0 after a change of mode. */
+#define FDCM_SHARD_TEMPLATES 0
+#define FDCM_SHARD_FRAMES 1
+int fdcm_sharded_set_mode(fdcm_sharded* s, int mode);
 int fdcm_sharded_submit(fdcm_sharded* s, const float* scene_lines, int64_t n_scene_lines, int64_t max_tmpl_lines,
                         int64_t max_scene_lines, int optimizer, int64_t batch_size, int64_t* ticket);
 int fdcm_sharded_submit_topk(fdcm_sharded* s, const float* scene_lines, int64_t n_scene_lines, int64_t max_tmpl_lines,

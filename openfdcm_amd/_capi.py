@@ -17,6 +17,7 @@ DEFAULT_OPTIMIZE, BATCH_OPTIMIZE, INDULGENT_OPTIMIZE = 0, 1, 2
 DEFAULT_PENALTY, EXPONENTIAL_PENALTY = 0, 1
 SHARDED_ALWAYS_COLLECTIVE = 1
 SHARDED_ALLOW_SAME_DEVICE = 2
+SHARD_TEMPLATES, SHARD_FRAMES = 0, 1
 
 MATCH_DTYPE = np.dtype([("tmpl_idx", "<i4"), ("score", "<f4"), ("transform", "<f4", (6,))])
 assert MATCH_DTYPE.itemsize == 32
@@ -88,6 +89,7 @@ SYMBOLS = [
     ("fdcm_sharded_search_topk", C.c_int, [_vp, _fp, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_float,
                                            C.c_int64, C.POINTER(_vp), _i64p]),
     ("fdcm_sharded_set_frames_in_flight", C.c_int, [_vp, C.c_int]),
+    ("fdcm_sharded_set_mode", C.c_int, [_vp, C.c_int]),
     ("fdcm_sharded_submit", C.c_int, [_vp, _fp, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int64, _i64p]),
     ("fdcm_sharded_submit_topk", C.c_int, [_vp, _fp, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_float,
                                            C.c_int64, _i64p]),

@@ -81,6 +81,7 @@ struct Job {
     int optimizer = 0, penalty = -1;
     float tau = 1.f;
     bool topk = false;
+    bool whole = false;   // frame-sharded mode: this device runs the frame over the WHOLE template list
 };
 
 struct FrameSlot {
@@ -105,6 +106,7 @@ struct Shard {
     int device = 0;
     int64_t begin = 0, end = 0;        // template range
     fdcm_templates* tset = nullptr;
+    fdcm_templates* full = nullptr;    // frame-sharded mode: the whole template list on this device (made by fdcm_sharded_set_mode)
     hipStream_t stream = nullptr;      // the collective's stream on this device
     std::vector<std::unique_ptr<FrameSlot>> slots;
     fdcm_build_timing bt{};            // of the frame collected last
@@ -137,9 +139,22 @@ struct fdcm_sharded {
     float coeff = 0.f, padding = 0.f;
     int distance = 0;
     int n_slots = 0;
+    int mode = FDCM_SHARD_TEMPLATES;    // fdcm_sharded_set_mode
+    std::vector<float> all_lines;       // host copy of the template list (the frame-sharded mode uploads it whole to every device)
+    std::vector<int64_t> all_offsets;
     int64_t next_ticket = 0;
-    std::vector<int64_t> slot_ticket;   // ticket held by every slot index (-1 = free)
+    // Ticket t lives in entry `entry_of(t)`: template shards: slot t % n_slots of EVERY shard (n_slots entries);
+    // frame shards: slot (t / N) % n_slots of shard t % N (N * n_slots entries, shard-major).
+    std::vector<int64_t> slot_ticket;   // ticket held by every entry (-1 = free)
     std::vector<Job> slot_job;          // what that ticket asked for (the tail of a top-k frame needs k)
+    size_t n_dev() const { return shards.size(); }
+    size_t entry_of(int64_t t) const {
+        return mode == FDCM_SHARD_FRAMES ? (size_t)(t % (int64_t)n_dev()) * (size_t)n_slots + (size_t)((t / (int64_t)n_dev()) % n_slots)
+                                         : (size_t)(t % n_slots);
+    }
+    size_t shard_of(int64_t t) const { return (size_t)(t % (int64_t)n_dev()); }               // frame shards only
+    size_t slot_of(int64_t t) const { return mode == FDCM_SHARD_FRAMES ? (size_t)((t / (int64_t)n_dev()) % n_slots) : (size_t)(t % n_slots); }
+    size_t n_entries() const { return mode == FDCM_SHARD_FRAMES ? n_dev() * (size_t)n_slots : (size_t)n_slots; }
     fdcm::DevBuf gathered;   // on the first device: all shards' records back to back
     int64_t collectives = 0; // grouped send/recv operations issued so far
     int64_t bytes_moved = 0; // bytes that crossed between devices (or through RCCL) so far
@@ -184,12 +199,14 @@ void run_slot_frame(fdcm_sharded* s, Shard& sh, FrameSlot& fs) {
         ok(fs.fm ? fdcm_featuremap_rebuild(fs.fm, scene, j.n_scene)
                  : fdcm_featuremap_build(scene, j.n_scene, s->depth, s->coeff, s->padding, s->distance, &fs.fm));
         fs.fm->shares_gpu = s->n_slots > 1;  // (tunes the next builds of this slot)
+        const fdcm_templates* tset = j.whole ? sh.full : sh.tset;
+        const int32_t base = j.whole ? 0 : (int32_t)sh.begin;
         int64_t cap = 0;
-        ok(fdcm_search_capacity(sh.tset, j.n_scene, j.maxT, j.maxS, &cap));
+        ok(fdcm_search_capacity(tset, j.n_scene, j.maxT, j.maxS, &cap));
         FDCM_HIP(hipSetDevice(sh.device));
         fs.block.reserve(std::max<size_t>(32, (size_t)cap * sizeof(fdcm_match)));
         int64_t n = 0;
-        ok(fdcm_search_device(fs.fm, sh.tset, scene, j.n_scene, j.maxT, j.maxS, j.optimizer, j.batch, (int32_t)sh.begin,
+        ok(fdcm_search_device(fs.fm, tset, scene, j.n_scene, j.maxT, j.maxS, j.optimizer, j.batch, base,
                               fs.block.as<fdcm_match>(), &n));
         (void)fdcm_featuremap_last_timing(fs.fm, &fs.bt);
         (void)fdcm_search_last_timing(fs.fm, &fs.st);
@@ -198,7 +215,7 @@ void run_slot_frame(fdcm_sharded* s, Shard& sh, FrameSlot& fs) {
         if (j.topk) {
             const int64_t kk = std::min<int64_t>(std::max<int64_t>(j.k, 0), n);
             fs.best.reserve(std::max<size_t>(32, (size_t)kk * sizeof(fdcm_match)));
-            fdcm::run_topk_device(fs.fm, sh.tset, fs.block.as<fdcm_match>(), n, (int32_t)sh.begin, j.penalty, j.tau, kk,
+            fdcm::run_topk_device(fs.fm, tset, fs.block.as<fdcm_match>(), n, base, j.penalty, j.tau, kk,
                                   fs.best.as<fdcm_match>());
             fs.n = kk;
             fs.send_from = fs.best.as<fdcm_match>();
@@ -267,52 +284,65 @@ void start_workers(fdcm_sharded* s, int n_slots) {
             }
         }
     s->n_slots = n_slots;
-    s->slot_ticket.assign((size_t)n_slots, -1);
-    s->slot_job.assign((size_t)n_slots, Job{});
+    s->slot_ticket.assign(s->n_entries(), -1);
+    s->slot_job.assign(s->n_entries(), Job{});
+}
+
+// Sizes the device memory of slot `si` of one shard for the frame: the record buffers take the frame's search capacity, the
+// slot's feature map every buffer its build and its search will ask for (reservations only: nothing is built or queued, and
+// a scene that cannot be built still fails where it always did -- in the frame, reported by its wait).
+void reserve_slot(fdcm_sharded* s, Shard& sh, size_t si, const Job& job) {
+    FrameSlot& fs = *sh.slots[si];
+    const fdcm_templates* tset = job.whole ? sh.full : sh.tset;
+    int64_t cap = 0;
+    if (fdcm_search_capacity(tset, job.n_scene, job.maxT, job.maxS, &cap) != FDCM_OK) throw std::string(fdcm_last_error());
+    FDCM_HIP(hipSetDevice(sh.device));
+    (void)fdcm_set_device(sh.device);
+    fs.block.reserve(std::max<size_t>(32, (size_t)cap * sizeof(fdcm_match)));
+    if (job.topk) fs.best.reserve(std::max<size_t>(32, (size_t)std::min<int64_t>(std::max<int64_t>(job.k, 0), cap) * sizeof(fdcm_match)));
+    if (!fs.fm && fdcm_featuremap_build(job.scene.data(), 0, s->depth, s->coeff, s->padding, s->distance, &fs.fm) != FDCM_OK)
+        throw std::string(fdcm_last_error());  // (an empty handle: no lines, no volume)
+    try {
+        BuildPlan plan;
+        make_build_plan(job.scene.data(), s->depth > 0 ? job.n_scene : 0, s->depth, s->coeff, s->padding, plan);
+        run_build(fs.fm, plan, 3, /*reserve_only=*/true);
+        reserve_search(fs.fm, tset, job.n_scene, job.maxT, job.maxS);
+    } catch (const std::string&) {  // e.g. a feature size the build rejects: the frame reports it
+    } catch (const HipError&) {     // an allocation that failed: the frame's own build asks again and reports it
+        (void)hipGetLastError();
+    }
+}
+
+void hand_over(FrameSlot& fs, const Job& job) {
+    std::unique_lock<std::mutex> lk(fs.mu);
+    fs.job = job;  // (a copy per shard: a few KB of scene lines)
+    fs.done = false;
+    fs.has_job = true;
+    fs.cv.notify_all();
 }
 
 int64_t submit_frame(fdcm_sharded* s, Job&& job) {
     DeviceGuard guard;  // the loop below switches devices on the caller's thread (also restored when it throws)
     if (s->n_slots == 0) start_workers(s, 1);
-    const size_t si = (size_t)(s->next_ticket % s->n_slots);
-    if (s->slot_ticket[si] >= 0) throw std::string("every frame slot holds a frame that has not been waited for");
+    const int64_t t = s->next_ticket;
+    const size_t ei = s->entry_of(t), si = s->slot_of(t);
+    if (s->slot_ticket[ei] >= 0) throw std::string("every frame slot holds a frame that has not been waited for");
     // Device memory of the slot is sized HERE, on the caller's thread, before its workers get the frame: an allocation is a
     // device-wide synchronisation, and the caller's thread is also the one that runs the exchange of earlier frames (in
-    // wait) -- so an allocation can never race a grouped send/recv in flight.  The record buffers take the frame's search
-    // capacity; the slot's feature map gets every buffer its build and its search will ask for (reservations only: nothing
-    // is built or queued here, and a scene that cannot be built still fails where it always did -- in the frame, reported
-    // by its wait).  A later frame with a larger feature size or more scene lines grows them here the same way.
-    for (auto& sh : s->shards) {
-        FrameSlot& fs = *sh.slots[si];
-        int64_t cap = 0;
-        if (fdcm_search_capacity(sh.tset, job.n_scene, job.maxT, job.maxS, &cap) != FDCM_OK) throw std::string(fdcm_last_error());
-        FDCM_HIP(hipSetDevice(sh.device));
-        (void)fdcm_set_device(sh.device);
-        fs.block.reserve(std::max<size_t>(32, (size_t)cap * sizeof(fdcm_match)));
-        if (job.topk) fs.best.reserve(std::max<size_t>(32, (size_t)std::min<int64_t>(std::max<int64_t>(job.k, 0), cap) * sizeof(fdcm_match)));
-        if (!fs.fm && fdcm_featuremap_build(job.scene.data(), 0, s->depth, s->coeff, s->padding, s->distance, &fs.fm) != FDCM_OK)
-            throw std::string(fdcm_last_error());  // (an empty handle: no lines, no volume)
-        try {
-            BuildPlan plan;
-            make_build_plan(job.scene.data(), s->depth > 0 ? job.n_scene : 0, s->depth, s->coeff, s->padding, plan);
-            run_build(fs.fm, plan, 3, /*reserve_only=*/true);
-            reserve_search(fs.fm, sh.tset, job.n_scene, job.maxT, job.maxS);
-        } catch (const std::string&) {  // e.g. a feature size the build rejects: the frame reports it
-        } catch (const HipError&) {     // an allocation that failed: the frame's own build asks again and reports it
-            (void)hipGetLastError();
-        }
+    // wait) -- so an allocation can never race a grouped send/recv in flight.  A later frame with a larger feature size or
+    // more scene lines grows the buffers here the same way.
+    if (s->mode == FDCM_SHARD_FRAMES) {  // the whole frame on one device, the whole template list
+        job.whole = true;
+        Shard& sh = s->shards[s->shard_of(t)];
+        reserve_slot(s, sh, si, job);
+        hand_over(*sh.slots[si], job);
+    } else {
+        for (auto& sh : s->shards) reserve_slot(s, sh, si, job);
+        for (auto& sh : s->shards) hand_over(*sh.slots[si], job);
     }
-    for (auto& sh : s->shards) {
-        FrameSlot& fs = *sh.slots[si];
-        std::unique_lock<std::mutex> lk(fs.mu);
-        fs.job = job;  // (a copy per shard: a few KB of scene lines)
-        fs.done = false;
-        fs.has_job = true;
-        fs.cv.notify_all();
-    }
-    s->slot_job[si] = std::move(job);
-    s->slot_job[si].scene.clear();
-    s->slot_ticket[si] = s->next_ticket;
+    s->slot_job[ei] = std::move(job);
+    s->slot_job[ei].scene.clear();
+    s->slot_ticket[ei] = t;
     return s->next_ticket++;
 }
 
@@ -389,11 +419,35 @@ fdcm_match* download(fdcm_sharded* s, int64_t total) {
 void collect_frame(fdcm_sharded* s, int64_t ticket, fdcm_match** out, int64_t* n_out) {
     *out = nullptr; *n_out = 0;
     if (ticket < 0 || s->n_slots == 0) throw std::string("unknown ticket");
-    const size_t si = (size_t)(ticket % s->n_slots);
-    if (s->slot_ticket[si] != ticket) throw std::string("unknown or already collected ticket");
-    s->slot_ticket[si] = -1;  // whatever happens below, the slot is free again
+    const size_t ei = s->entry_of(ticket), si = s->slot_of(ticket);
+    if (s->slot_ticket[ei] != ticket) throw std::string("unknown or already collected ticket");
+    s->slot_ticket[ei] = -1;  // whatever happens below, the slot is free again
+    const Job& job = s->slot_job[ei];
+    if (s->mode == FDCM_SHARD_FRAMES) {
+        // the frame ran whole on one device: its records (or its k best, already in order) go to the host from there, no exchange
+        Shard& sh = s->shards[s->shard_of(ticket)];
+        FrameSlot& fs = *sh.slots[si];
+        {
+            std::unique_lock<std::mutex> lk(fs.mu);
+            fs.cv.wait(lk, [&] { return fs.done; });
+        }
+        sh.bt = fs.bt; sh.st = fs.st;
+        if (fs.rc != FDCM_OK) throw std::string("shard on device ") + std::to_string(sh.device) + ": " + fs.error;
+        fdcm_match* res = result_acquire(std::max<size_t>(1, (size_t)fs.n) * sizeof(fdcm_match));
+        try {
+            FDCM_HIP(hipSetDevice(sh.device));
+            if (fs.n) {
+                records_to_host(sh.stream, fs.send_from, fs.n, res);
+                FDCM_HIP(hipStreamSynchronize(sh.stream));
+            }
+        } catch (...) {
+            result_release(res);
+            throw;
+        }
+        *out = res; *n_out = fs.n;
+        return;
+    }
     wait_slot(s, si);
-    const Job& job = s->slot_job[si];
     const int64_t total = gather_to_first(s, si);  // top-k mode: at most k records per shard cross the links
     fdcm_match* all = download(s, total);
     if (job.topk) {
@@ -432,6 +486,7 @@ void destroy_sharded(fdcm_sharded* s) {
         (void)hipSetDevice(sh.device);
         if (sh.stream) { (void)hipStreamSynchronize(sh.stream); (void)hipStreamDestroy(sh.stream); }
         if (sh.tset) (void)fdcm_templates_free(sh.tset);
+        if (sh.full) (void)fdcm_templates_free(sh.full);
     }
     if (!s->shards.empty()) (void)hipSetDevice(s->shards[0].device);
     s->gathered.release();
@@ -459,6 +514,8 @@ int fdcm_sharded_create(const int* devices, int n_devices, const float* tmpl_lin
         s->always_collective = (flags & FDCM_SHARDED_ALWAYS_COLLECTIVE) != 0;
         s->same_device_ok = (flags & FDCM_SHARDED_ALLOW_SAME_DEVICE) != 0;
         if (s->same_device_ok && s->always_collective) throw std::string("ALLOW_SAME_DEVICE and ALWAYS_COLLECTIVE exclude each other");
+        s->all_offsets.assign(offsets, offsets + n_templates + 1);
+        if (s->all_offsets.back() > 0) s->all_lines.assign(tmpl_lines, tmpl_lines + 4 * s->all_offsets.back());
         s->shards.resize((size_t)n_devices);
         std::vector<int> devs((size_t)n_devices);
         for (int i = 0; i < n_devices; ++i) {
@@ -510,6 +567,30 @@ int fdcm_sharded_set_frames_in_flight(fdcm_sharded* s, int n_frames) {
         for (int64_t t : s->slot_ticket)
             if (t >= 0) throw std::string("frames are in flight: collect them with fdcm_sharded_wait first");
         if (n_frames != s->n_slots) start_workers(s, n_frames);
+    });
+}
+
+int fdcm_sharded_set_mode(fdcm_sharded* s, int mode) {
+    DeviceGuard guard;
+    return guarded_s([&] {
+        if (!s) throw std::string("null handle");
+        if (mode != FDCM_SHARD_TEMPLATES && mode != FDCM_SHARD_FRAMES) throw std::string("unknown sharding mode");
+        for (int64_t t : s->slot_ticket)
+            if (t >= 0) throw std::string("frames are in flight: collect them with fdcm_sharded_wait first");
+        if (mode == FDCM_SHARD_FRAMES)
+            for (auto& sh : s->shards) {  // the whole list on every device, once
+                if (sh.full) continue;
+                if (fdcm_set_device(sh.device) != FDCM_OK) throw std::string(fdcm_last_error());
+                if (fdcm_templates_create(s->all_lines.empty() ? nullptr : s->all_lines.data(), s->all_offsets.data(),
+                                          (int64_t)s->all_offsets.size() - 1, &sh.full) != FDCM_OK)
+                    throw std::string(fdcm_last_error());
+            }
+        if (mode != s->mode) {
+            const int n = std::max(1, s->n_slots);
+            s->mode = mode;
+            s->next_ticket = 0;  // tickets restart: which device and slot a ticket runs on depends on the mode
+            start_workers(s, n);
+        }
     });
 }
 

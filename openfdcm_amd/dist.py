@@ -119,6 +119,51 @@ def gather_topk(local_topk, k, device, group=None, dst=0):
     return merge_topk([res], k)
 
 
+class FrameShards:
+    """Frame sharding across the ranks (the other way to use N GPUs, for a STREAM of frames): frame f of the stream runs
+    whole on rank f % world with the whole template list, so nothing is exchanged on the data path and the job's rate is
+    N times one GPU's (template shards are bounded by the build every rank repeats).  This class is the bookkeeping only:
+    which frames are a rank's, the job's match count, and every frame's digest on rank 0 (for a parity gate)."""
+
+    def __init__(self, rank, world_size, group=None):
+        self.rank, self.world, self.group = rank, world_size, group
+
+    def frame_of(self, local_index):
+        """Position in the stream of this rank's `local_index`-th frame."""
+        return local_index * self.world + self.rank
+
+    def mine(self, n_frames):
+        """The frames of a stream of n_frames that this rank runs."""
+        return range(self.rank, n_frames, self.world)
+
+    def total(self, local_count, device):
+        """Sum of a per-rank count over the ranks (one 8-byte all-reduce, after the timed region)."""
+        if self.world == 1 and not dist.is_initialized():
+            return int(local_count)
+        t = torch.tensor([int(local_count)], dtype=torch.int64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return int(t.item())
+
+    @staticmethod
+    def digest(records, below_template=None):
+        """(record count, sha256 of the bytes) of a frame's match records, optionally of the templates below an index only."""
+        import hashlib
+        r = np.asarray(records)
+        if below_template is not None:
+            r = r[r["tmpl_idx"] < below_template]
+        return len(r), hashlib.sha256(np.ascontiguousarray(r).tobytes()).hexdigest()
+
+    def gather_digests(self, frames, below_template=None, dst=0):
+        """frames: this rank's [(tag, records)] in the order it ran them.  Returns on rank `dst` a list per rank of
+        (tag, count, sha256), None elsewhere."""
+        mine = [(tag,) + self.digest(rec, below_template) for tag, rec in frames]
+        if not dist.is_initialized():
+            return [mine]
+        out = [None] * self.world if self.rank == dst else None
+        dist.gather_object(mine, out, dst=dst, group=self.group)
+        return out
+
+
 class FrameGatherer:
     """Persistent buffers for gathering one frame's match records per call (the per-frame path of the
     pipeline, where allocations, pageable copies and host-side concatenation would cost more than

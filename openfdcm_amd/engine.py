@@ -326,6 +326,12 @@ class ShardedEngine:
                                                        -1 if penalty is None else penalty, tau, k, C.byref(out), C.byref(n)))
         return _adopt_matches(out, n.value)
 
+    def set_mode(self, mode):
+        """capi.SHARD_TEMPLATES (default: every frame on every device, template ranges, one exchange per frame) or
+        capi.SHARD_FRAMES (ticket t whole on device t % n_devices over the whole template list, no exchange).  Only while
+        no frame is in flight; tickets restart at 0."""
+        capi.check(capi.lib().fdcm_sharded_set_mode(self._h, int(mode)))
+
     def set_frames_in_flight(self, n_frames):
         """Frame slots per device (1..16); only while no frame is in flight."""
         capi.check(capi.lib().fdcm_sharded_set_frames_in_flight(self._h, int(n_frames)))

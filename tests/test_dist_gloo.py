@@ -178,3 +178,51 @@ def test_sharded_topk_world2(tmp_path):
     out = str(tmp_path / "n.npy")
     mp.spawn(_topk_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     assert int(np.load(out)[0]) == 9
+
+
+def _frames_worker(rank, world, port, out_path):
+    """Frame shards (dist.FrameShards, what bench.py --scaling frames and fdcm_sharded_set_mode(FRAMES) do): frame f of the
+    stream whole on rank f % world, nothing exchanged on the data path; the count and the digests reach rank 0."""
+    from oracle import oracle as O
+    from openfdcm_amd.dist import FrameShards
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        S = 128
+        scenes = [synthetic.scene(S, 24 + 3 * i, 40 + i) for i in range(3)]
+        tmpls = synthetic.templates(6, 9, S, 6)
+        fs = FrameShards(rank, world)
+        n_frames = 7
+        assert list(fs.mine(n_frames)) == [f for f in range(n_frames) if f % world == rank]
+        assert [fs.frame_of(i) for i in range(len(fs.mine(n_frames)))] == list(fs.mine(n_frames))
+        ran, count = [], 0
+        for f in fs.mine(n_frames):
+            sc = scenes[f % len(scenes)]
+            rec = O.search(O.build(sc, depth=12, coeff=5.0, padding=1.0), tmpls, sc, 3, 3, kind=O.BATCH_OPTIMIZE, batch=10).astype(MATCH_DTYPE)
+            ran.append((f, rec))
+            count += len(rec)
+        total = fs.total(count, torch.device("cpu"))
+        dig = fs.gather_digests(ran, below_template=4)
+        if rank == 0:
+            want = []
+            for sc in scenes:
+                r = O.search(O.build(sc, depth=12, coeff=5.0, padding=1.0), tmpls, sc, 3, 3, kind=O.BATCH_OPTIMIZE, batch=10).astype(MATCH_DTYPE)
+                want.append(r)
+            assert total == sum(len(want[f % 3]) for f in range(n_frames))
+            assert len(dig) == world and sorted(t for d in dig for t, _, _ in d) == list(range(n_frames))
+            for r, frames in enumerate(dig):
+                assert [t % world for t, _, _ in frames] == [r] * len(frames)
+                for t, n, h in frames:
+                    assert (n, h) == FrameShards.digest(want[t % 3], 4), (r, t)
+            np.save(out_path, np.array([total]))
+        else:
+            assert dig is None
+    finally:
+        dist.destroy_process_group()
+
+
+def test_frame_shards_world2(tmp_path):
+    out = str(tmp_path / "frames.npy")
+    mp.spawn(_frames_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert np.load(out)[0] > 0

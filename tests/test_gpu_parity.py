@@ -892,6 +892,59 @@ def test_sharded_engine_several_shards_on_one_device(amd):
         ShardedEngine(synthetic.templates(4, 5, 128, 3), devices=[0, 0])
 
 
+def test_sharded_engine_frame_shards(amd):
+    """fdcm_sharded_set_mode(FDCM_SHARD_FRAMES): ticket t runs whole on shard t % N (here two and three shards on the one
+    device, through the ALLOW_SAME_DEVICE hook) over the WHOLE template list; every frame -- full list and top-k -- equals the
+    single-device call on its own scene, N x frames-in-flight tickets may be outstanding, nothing is exchanged, and the
+    engine switches back to template shards."""
+    from openfdcm_amd import synthetic, _capi
+    from openfdcm_amd.engine import DeviceFeatureMap, DeviceTemplates, ShardedEngine, search_raw, topk
+    S = 256
+    tmpls = synthetic.templates(23, 12, S, 91)
+    scenes = [synthetic.scene(S, 30 + 6 * i, 80 + i) for i in range(5)] + [np.zeros((4, 0), np.float32)]
+    tset = DeviceTemplates(tmpls)
+    fm = DeviceFeatureMap.build(scenes[0], depth=16, coeff=5.0, padding=1.0, distance=O.L2)
+    want, want_top = [], []
+    for sc in scenes:
+        fm.rebuild(sc)
+        want.append(np.array(search_raw(fm, tset, sc, 4, 4, _capi.BATCH_OPTIMIZE, 10), copy=True))
+        want_top.append(np.array(topk(fm, tset, 9, 1, 1.5), copy=True) if sc.shape[1] else want[-1][:0])
+    orc = O.build(scenes[1], depth=16, coeff=5.0, padding=1.0, distance=O.L2, nthreads=4)
+    assert want[1].tobytes() == np.asarray(O.search(orc, tmpls, scenes[1], 4, 4, kind=O.BATCH_OPTIMIZE, batch=10, nthreads=4)).tobytes()
+    for shards, in_flight in ((2, 1), (3, 2)):
+        eng = ShardedEngine(tmpls, devices=[0] * shards, depth=16, coeff=5.0, padding=1.0, distance=O.L2, allow_same_device=True)
+        assert eng.search(scenes[0], 4, 4).tobytes() == want[0].tobytes()      # template shards first
+        eng.set_frames_in_flight(in_flight)
+        eng.set_mode(_capi.SHARD_FRAMES)
+        cap = shards * in_flight
+        pend = []
+        for step, i in enumerate(list(range(len(scenes))) * 3):
+            if len(pend) == cap:
+                t, j, top = pend.pop(0)
+                assert eng.wait(t).tobytes() == (want_top[j] if top else want[j]).tobytes(), (shards, t, j, top)
+            top = step % 4 == 3
+            t = eng.submit(scenes[i], 4, 4, _capi.BATCH_OPTIMIZE, 10, k=9 if top else None, penalty=1, tau=1.5)
+            assert t == step
+            pend.append((t, i, top))
+        with pytest.raises(_capi.FdcmError, match="not been waited for"):
+            eng.submit(scenes[0], 4, 4)
+        with pytest.raises(_capi.FdcmError, match="in flight"):
+            eng.set_mode(_capi.SHARD_TEMPLATES)
+        for t, j, top in reversed(pend):                                          # any order
+            assert eng.wait(t).tobytes() == (want_top[j] if top else want[j]).tobytes(), (shards, t, j, top)
+        with pytest.raises(_capi.FdcmError, match="ticket"):
+            eng.wait(0)
+        assert eng.search(scenes[2], 4, 4).tobytes() == want[2].tobytes()
+        assert eng.search_topk(scenes[3], 4, 4, 9, penalty=1, tau=1.5).tobytes() == want_top[3].tobytes()
+        info = eng.info()
+        assert info["collectives"] == 0 and info["bytes_moved"] == 0
+        eng.set_mode(_capi.SHARD_TEMPLATES)
+        assert eng.search(scenes[4], 4, 4).tobytes() == want[4].tobytes()
+        with pytest.raises(_capi.FdcmError, match="mode"):
+            eng.set_mode(7)
+        eng.close()
+
+
 def test_sharded_engine_several_devices(amd):
     """fdcm_sharded_* with more than one device -- ncclCommInitAll over several devices, workers per device,
     cross-device send/recv into the gathered array at per-shard offsets, the top-k merge across shards, uneven and empty
@@ -923,6 +976,14 @@ def test_sharded_engine_several_devices(amd):
                 assert eng.search_topk(sc, 4, 4, k, penalty=1, tau=1.5).tobytes() == topk(fm, tset, k, 1, 1.5).tobytes(), (T, k)
         info = eng.info()
         assert info["shard_begin"][0] == 0 and info["shard_begin"][-1] == T and info["collectives"] > 0
+        # frame shards over the real devices: ticket t whole on device t % nd, nothing exchanged
+        eng.set_mode(_capi.SHARD_FRAMES)
+        moved = eng.info()["bytes_moved"]
+        tickets = [(eng.submit(scenes[i % 2], 4, 4, _capi.BATCH_OPTIMIZE, 10), scenes[i % 2]) for i in range(2 * nd)]
+        for t, sc in tickets:
+            fm.rebuild(sc)
+            assert eng.wait(t).tobytes() == search_raw(fm, tset, sc, 4, 4, _capi.BATCH_OPTIMIZE, 10).tobytes(), (T, t)
+        assert eng.info()["bytes_moved"] == moved
         eng.close()
 
 
@@ -953,6 +1014,18 @@ def test_bench_force_dist_runs_the_rccl_gather_and_passes_its_parity_gate(amd):
     doc = json.loads(out.stdout.strip().splitlines()[-1])
     assert doc["parity_gate"] == "ok" and doc["n_gpus"] == 1 and doc["config"]["matches_per_step"] > 1000
     assert doc["roofline"]["frac"] > 0 and doc["roofline_search"]["achieved"] > 0 and doc["cpu_baseline"]["cores"] >= 1
+    assert doc["config"]["distinct_scenes"] == 4 and "all 8 timed frames" in doc["parity_gate_detail"]
+    assert doc["roofline"]["same_scene_ms"] > 0 and doc["dt3_build_ms"] >= doc["dt3_build_kernels_ms"] > 0
+    assert doc["api"]["parity_gate"] == "ok" and 0 < doc["api_frame_ms"] < 50
+    # --scaling frames with one rank through the process group: the frame-sharded schedule, the summed match count and the
+    # digest gate (with N ranks: every rank's own frames)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--force-dist", "--scaling", "frames", "--steps", "8", "--warmup", "2",
+                          "--templates", "120", "--cpu-sample", "40", "--cpu-reps", "1", "--single-frames", "3", "--api-frames", "0"],
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+    doc = json.loads(out.stdout.strip().splitlines()[-1])
+    assert doc["parity_gate"] == "ok" and doc["config"]["sharding"] == "frames" and doc["scaling"] == "weak"
+    assert "every rank's own frames" in doc["parity_gate_detail"] and doc["scaling_bounds"]["frames"]["8"] == 8.0
 
 
 def test_bench_two_gpus_gates_the_gathered_list(amd):
@@ -979,6 +1052,12 @@ def test_bench_two_gpus_gates_the_gathered_list(amd):
         assert doc["parity_gate"] == "ok" and doc["n_gpus"] == 2 and doc["scaling"] == scaling
         assert "the gathered list of all ranks" in doc["parity_gate_detail"] and doc["cpu_baseline"]["cores"] >= 1
         assert doc["config"]["templates_total"] == (240 if scaling == "weak" else 120)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "2", "--scaling", "frames",
+                          "--templates", "120", "--cpu-reps", "1", "--single-frames", "3", "--api-frames", "0"], capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+    doc = json.loads([l for l in out.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert doc["parity_gate"] == "ok" and doc["n_gpus"] == 2 and doc["config"]["sharding"] == "frames"
+    assert "all 16 timed frames" in doc["parity_gate_detail"] and doc["config"]["templates_total"] == 120
 
 
 def test_envelope_quotient_is_the_division_for_every_operand_pair(amd, tmp_path):
