@@ -10,7 +10,7 @@ cd /tmp
 pass() {  # pass <name> <counters...> : one rocprofv3 --pmc pass of the one-frame bench
   local name=$1; shift
   rm -rf /tmp/sq_$name
-  rocprofv3 --kernel-trace --pmc "$@" -d /tmp/sq_$name -o sq --output-format csv -- python3 $R/bench.py --frames 1 --steps 5 --warmup 2 --cpu-sample 0 --single-frames 0 > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc "$@" -d /tmp/sq_$name -o sq --output-format csv -- python3 $R/bench.py --frames 1 --steps 5 --warmup 2 --cpu-sample 0 --single-frames 0 --api-frames 0 > /dev/null 2>&1
   cp "$(find /tmp/sq_$name -name '*counter_collection.csv' | head -1)" $OUT/$name.csv
 }
 pass sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
@@ -30,7 +30,7 @@ for f in sorted(os.listdir(out)):
 summ = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in res.items()}
 import hashlib
 so = os.path.join(os.environ.get('FDCM_REPO', '.'), 'openfdcm_amd', 'libfdcm_hip.so')
-doc = {"source": "rocprofv3 --kernel-trace --pmc <set> (one pass per set) -- python3 bench.py --frames 1 --steps 5 --warmup 2 --cpu-sample 0 --single-frames 0; averages per launch",
+doc = {"source": "rocprofv3 --kernel-trace --pmc <set> (one pass per set) -- python3 bench.py --frames 1 --steps 5 --warmup 2 --cpu-sample 0 --single-frames 0 --api-frames 0; averages per launch",
        "so_sha256_16": hashlib.sha256(open(so, 'rb').read()).hexdigest()[:16] if os.path.exists(so) else None, "kernels": summ}
 json.dump(doc, open(os.path.join(out, 'summary.json'), 'w'), indent=1)
 for k, d in summ.items():
