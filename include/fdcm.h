@@ -318,6 +318,11 @@ int fdcm_selftest_sweep_ranges(int n_seeded_columns);
  * small enough to be resident at once take no order and count in neither.  Lets a test see that a frame slot whose buffers
  * are reserved before every frame (fdcm_sharded_submit) keeps its history. */
 int fdcm_selftest_sweep_order_counts(int64_t* from_history, int64_t* from_proxy);
+/* Column ranges that waves of the balanced L2 / L2^2 sweep took over from slower ones, over all builds of this handle's
+ * present scratch (dynamic cuts: a wave out of columns begins a new range in the middle of the longest stretch nobody has
+ * started; by default only where one blocking build has the GPU to itself, FDCM_SWEEP_STEAL=<blocks> forces a threshold,
+ * 0 = never).  Lets a test see that the path it means to exercise ran. */
+int fdcm_selftest_sweep_steals(fdcm_featuremap* fm, int64_t* count);
 
 #ifdef __cplusplus
 }

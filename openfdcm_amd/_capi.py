@@ -107,6 +107,7 @@ SYMBOLS = [
     ("fdcm_orientation_bins_mode", C.c_int, []),
     ("fdcm_selftest_sweep_ranges", C.c_int, [C.c_int]),
     ("fdcm_selftest_sweep_order_counts", C.c_int, [_i64p, _i64p]),
+    ("fdcm_selftest_sweep_steals", C.c_int, [_vp, _i64p]),
 ]
 
 _lib = None

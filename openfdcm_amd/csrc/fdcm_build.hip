@@ -715,7 +715,7 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after, bool 
         size_t off = 0;
         auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
         const size_t o_ent = take(slots * NRr * sizeof(EnvEntry)), o_own = take(slots * NRr * sizeof(OwnEntry));
-        const size_t o_ord = take((size_t)nchunks * 4), o_cost = take((size_t)nchunks * 4);
+        const size_t o_ord = take((size_t)nchunks * 4), o_cost = take((size_t)nchunks * 4), o_steals = take(256);
         const void* stack_before = fm->stack.p;
         fm->stack.reserve(off);
         char* sp = (char*)fm->stack.p;
@@ -733,6 +733,17 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after, bool 
         sb.ent = (EnvEntry*)(sp + o_ent); sb.own = (OwnEntry*)(sp + o_own);
         sb.order = (have_cost || proxy_order) ? (const int*)(sp + o_ord) : nullptr;
         sb.cost = (int*)(sp + o_cost);
+        // Dynamic cuts (a wave out of columns begins a new range in what nobody has started): they shorten the heaviest
+        // workgroup's chain and add junctions, i.e. work -- worth it where the kernel lasts as long as its slowest workgroup
+        // (all workgroups resident at once, the GPU to this handle), not where workgroups queue for the CUs or frames of a
+        // pipeline share them (config 2: one blocking build 0.354 -> 0.333 ms over four scenes; four frames in flight 69.7 ->
+        // 68.4 M matches/s; config 3: 0.76 -> 0.81 ms).  FDCM_SWEEP_STEAL=<blocks> forces a threshold (0: never) for the tests.
+        sb.steal_min = (!fm->shares_gpu && nchunks <= 2L * device_cus(fm->device)) ? -1 : 0;  // -1: the kernel's default threshold
+        sb.steals = (int*)(sp + o_steals);
+        if (!reserve_only) {
+            if (fm->sweep_steals != sb.steals) FDCM_HIP(hipMemsetAsync(sp + o_steals, 0, 256, st));  // a new scratch (or shape): count from 0
+            fm->sweep_steals = sb.steals;
+        }
         sb.eslots = (int)slots; sb.lslots = (int)slots;
         sb.colmask = (const unsigned long long*)fm->colmask.p;
         fm->k2_cost_chunks = nchunks; fm->k2_cost_w = W;

@@ -592,6 +592,18 @@ int fdcm_selftest_sweep_order_counts(int64_t* from_history, int64_t* from_proxy)
         fdcm::sweep_order_counts(from_history, from_proxy);
     });
 }
+int fdcm_selftest_sweep_steals(fdcm_featuremap* fm, int64_t* count) {
+    return guarded([&] {
+        require(fm && count, "null argument");
+        *count = 0;
+        if (!fm->sweep_steals) return;
+        finish_build(fm);
+        FDCM_HIP(hipSetDevice(fm->device));
+        int v = 0;
+        FDCM_HIP(hipMemcpy(&v, fm->sweep_steals, sizeof(int), hipMemcpyDeviceToHost));
+        *count = v;
+    });
+}
 int fdcm_selftest_sweep_ranges(int n_seeded_columns) { return fdcm::sweep_ranges(n_seeded_columns, fdcm::sweep_min_cols()); }
 
 }  // extern "C"

@@ -119,6 +119,7 @@ struct fdcm_featuremap {
     int64_t depth_param = 0;
     float coeff = 0, padding = 0;
     int distance = 0;
+    int* sweep_steals = nullptr;  // device counter inside `stack`: ranges the L2 sweep's waves took over so far (fdcm_selftest_sweep_steals)
     long k2_cost_chunks = 0; int k2_cost_w = 0;  // the L2 sweep's per-chunk costs in `stack` are those of a build with this shape
     int off_m = 0, off_steps = 0;  // the group table in `offtab` is valid for this depth and feature width
     bool build_pending = false;  // the last build is queued on `stream` but has not been waited for

@@ -18,6 +18,10 @@ struct SweepBuf {
     int eslots, lslots;
     const unsigned long long* colmask;    // [slice][(W + 63) / 64]: the slice's seeded columns (k_coldesc_tile)
     int min_cols;                         // seeded columns a range holds at least (set by the launcher)
+    int steal_min;                        // a wave out of columns starts a new range in a stretch of at least this many unclaimed blocks
+                                          // (0: never, ranges of equal count only; < 0: the launcher's default; FDCM_SWEEP_STEAL overrides both)
+    int steal_cols;                       // .. that holds this many columns at least
+    int* steals;                          // [0]: ranges taken over so far (all launches of the handle), or null
 #ifdef FDCM_LAB
     int lane_cursors;                     // lab builds: the local run with a column cursor per lane (FDCM_SWEEP_LOCAL=cursors)
     long long* lab;                       // lab builds (make LAB=1): 16 clock stamps / counters per (chunk, wave), or null

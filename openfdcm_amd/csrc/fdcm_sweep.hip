@@ -72,14 +72,27 @@ struct Ring {
     __device__ __forceinline__ void put_z(int i, int c, float z) const { p[2 * kPlane + (i & (kRing - 1)) * kNT + c] = z; }
 };
 
+// Ranges of a row.  A workgroup starts with S <= kSeg ranges of equal column count, one per wave; a wave that runs out of
+// columns takes over the far half of the longest stretch of columns nobody has started yet, with a fresh stack, as a new range
+// (dynamic cuts: the exact-owner theorem allows any cut).  Columns are handed out in blocks: a wave claims the next block of its
+// stretch when it gets there (an atomic OR on a bit map in LDS), and stops where somebody else's range begins.
+static constexpr int kMaxR = 16;     // ranges per row at most (initial + taken over)
+static constexpr int kMaxBlk = 128;  // claim blocks per slice at most (two 64-bit words)
+static constexpr int kStealMin = 2;   // .. and kStealCols columns
+static constexpr int kStealCols = 16;  // blocks an unclaimed stretch must have for a wave out of columns to begin a new range in its middle (FDCM_SWEEP_STEAL)
 struct SweepLds {
     unsigned long long smask[64];    // the slice's seeded columns, 64 per word (W <= 4096)
-    int t_cnt[kSeg][64];             // entries of the local stack of (range, row)
-    int t_base[kSeg][64];            // of which [t_base, t_cnt) are in the LDS ring (all of them are in HBM too)
-    int t_lo[kSeg][64], t_hi[kSeg][64];  // after the merge: the entries [t_lo, t_hi] of the local stack are on the row's stack
-    int t_prev[kSeg][64];            // the range below this one on the row's stack at the time it landed
-    int t_K[kSeg][64];               // the walk: stream index -> HBM slot offset of (range, row)
-    int s_slot0[kSeg];               // first HBM slot of a range's entries (its first column: ranges are disjoint)
+    unsigned long long claim[2];     // blocks of columns that have an owner
+    unsigned short blk_q[kMaxBlk + 2];  // column (position) at which block b begins; blk_q[nblk] = W
+    short t_cnt[kMaxR][64];          // entries of the local stack of (range, row)
+    short t_base[kMaxR][64];         // of which [t_base, t_cnt) are in the LDS ring (all of them are in HBM too)
+    short t_lo[kMaxR][64], t_hi[kMaxR][64];  // after the merge: the entries [t_lo, t_hi] of the local stack are on the row's stack
+    signed char t_prev[kMaxR][64];   // the range below this one on the row's stack at the time it landed
+    short t_K[kMaxR][64];            // the walk: stream index -> HBM slot offset of (range, row)
+    int s_slot0[kMaxR];              // first HBM slot of a range's entries (its first column: ranges are disjoint); INT_MAX: no such range
+    int r_wave[kMaxR];               // the wave whose ring columns hold the range's top entries
+    int r_pos[kMaxR];                // rank of the range by first column (the merge takes them from left to right)
+    int n_ranges;                    // range ids handed out so far
     int s_lcount[64];                // owner entries per row
     int s_pi[kSeg][64];              // [p - 1][row]: list index that owns the first pixel of fill part p
 #ifdef FDCM_LAB
@@ -94,6 +107,20 @@ __device__ __forceinline__ int select_column(const unsigned long long* smask, in
     while (__popcll(mk) <= t) { t -= __popcll(mk); ++b; mk = uni64(smask[b]); }
     for (; t > 0; --t) mk &= mk - 1ull;
     return b * 64 + __ffsll((long long)mk) - 1;
+}
+
+// the same for a rank that differs from lane to lane (no scalar broadcast of the mask words; the bit inside the word by halving)
+__device__ __forceinline__ int select_column_lane(const unsigned long long* smask, int t) {
+    int b = 0;
+    unsigned long long mk = smask[0];
+    while (__popcll(mk) <= t) { t -= __popcll(mk); ++b; mk = smask[b]; }
+    int pos = 0;
+#pragma unroll
+    for (int w = 32; w >= 1; w >>= 1) {
+        const int c = __popcll(mk & ((1ull << w) - 1ull));
+        if (t >= c) { t -= c; mk >>= w; pos += w; }
+    }
+    return b * 64 + pos;
 }
 
 // ---- the literal construction over the seeded columns [q0, ql] of the slice, bottom = q0 (imgproc.h:100-121)
@@ -125,8 +152,22 @@ __device__ __forceinline__ void local_finish(const Ring ring, EnvEntry* __restri
         base = min(base, want);
     }
 }
-__device__ __forceinline__ void local_run(const uint4* __restrict__ dp, int W, const unsigned long long* smask, int q0, int ql, int lane,
-                                          int y, int tid, const Ring ring, EnvEntry* __restrict__ ent, int& cnt_out, int& base_out, long long* lab) {
+// A block of columns gets its owner: true when this wave is the one (wave-uniform; one LDS atomic by lane 0)
+__device__ __forceinline__ bool claim_block(SweepLds& L, int b, int lane) {
+    unsigned long long old = 0ull;
+    if (lane == 0) old = atomicOr(&L.claim[b >> 6], 1ull << (b & 63));
+    old = uni64(old);
+    return ((old >> (b & 63)) & 1ull) == 0ull;
+}
+// The run starts at the first column of block b0 (claimed by the caller) and goes on through the blocks behind it for as long
+// as it is the first to claim them: it ends where another range begins, or at the slice's last column.
+// (bend < 0: dynamic; bend >= 0: no claims at all, the run covers the blocks [b0, bend) -- ranges of equal count, FDCM_SWEEP_STEAL=0)
+__device__ __forceinline__ void local_run(const uint4* __restrict__ dp, int W, SweepLds& L, int b0, int nblk, int bend, int lane,
+                                          int y, int tid, const Ring ring, EnvEntry* __restrict__ ent_row, int& cnt_out, int& base_out, int& q0_out, long long* lab) {
+    const unsigned long long* smask = L.smask;
+    const int q0 = __builtin_amdgcn_readfirstlane((int)L.blk_q[b0]);
+    EnvEntry* __restrict__ ent = ent_row + q0;
+    q0_out = q0;
 #ifdef FDCM_LAB
     long long lab_cols = 0, lab_pop = 0, lab_evict = 0;
     const long long lab_t0 = __builtin_amdgcn_s_memtime();
@@ -150,21 +191,48 @@ __device__ __forceinline__ void local_run(const uint4* __restrict__ dp, int W, c
     };
     const unsigned lanebase = (unsigned)(size_t)(ring.p + tid);  // LDS byte address of this lane's ring entry 0, plane 0 (entry i: + i * 2048; planes 16384 apart)
     static_assert(kNT * sizeof(float) == 2048 && Ring::kPlane * sizeof(float) == 16384, "the pop loop below shifts the ring index by 11 and has the plane offsets written out");
-    const int qlo = q0 + 1, qhi = ql;
-    if (qlo <= qhi) {
+    const int qlo = q0 + 1;
+    int qhi = __builtin_amdgcn_readfirstlane((int)L.blk_q[bend >= 0 ? bend : b0 + 1]) - 1;  // last position of the stretch claimed so far
+    if (bend >= 0) nblk = 0;  // (nothing to ask for)
+    {
         // The range's seeded columns in order (columns without a seed in the slice never own a pixel: skipped).  A column's
         // descriptor is the same 16 bytes for every lane: a scalar load into SGPRs (left to itself the compiler fetches the seed
         // word with a vector load and waits for every store in flight), issued one column ahead -- it lands behind the waits
         // of this column's pop loop instead of being waited for on the spot (~250 cycles per column).
-        const int whi = qhi >> 6;
-        int wd = qlo >> 6;
-        unsigned long long mk = uni64(smask[wd]) & (~0ull << (qlo & 63));
+        int bcur = b0;
+        int whi = qhi >> 6;
+        int wd = min(qlo >> 6, whi);
+        unsigned long long mk = qlo <= qhi ? uni64(smask[wd]) & (~0ull << (qlo & 63)) : 0ull;
         if (wd == whi) mk &= ~0ull >> (63 - (qhi & 63));
-        auto advance = [&]() {  // to the next word of the range with a seeded column, if any
-            while (mk == 0ull && wd < whi) {
-                ++wd;
-                mk = uni64(smask[wd]);
+        // The block behind the current one is asked for on entering the current one: the atomic's answer and the block's bounds
+        // are in registers long before the stretch runs out (they land behind the waits of the pop loops in between), so the
+        // hand-over from block to block costs no trip to LDS on the column chain.  (A wave so holds its block and the next.)
+        unsigned long long pend_old = 0ull;  // lane 0: the claim word as it was before this wave's OR
+        unsigned pend_q = 0u, pend_qn = 0u;  // first column of block bcur + 1, of block bcur + 2
+        auto ask_next = [&]() {
+            if (bcur + 1 < nblk) {
+                if (lane == 0) pend_old = atomicOr(&L.claim[(bcur + 1) >> 6], 1ull << ((bcur + 1) & 63));
+                pend_q = L.blk_q[bcur + 1]; pend_qn = L.blk_q[bcur + 2];
+            }
+        };
+        ask_next();
+        auto advance = [&]() {  // to the next word of the stretch with a seeded column; at its end, on into the next block if it is this wave's
+            for (;;) {
+                while (mk == 0ull && wd < whi) {
+                    ++wd;
+                    mk = uni64(smask[wd]);
+                    if (wd == whi) mk &= ~0ull >> (63 - (qhi & 63));
+                }
+                if (mk != 0ull || bcur + 1 >= nblk) return;
+                if (((uni64(pend_old) >> ((bcur + 1) & 63)) & 1ull) != 0ull) return;  // it had an owner already: the range ends here
+                ++bcur;
+                const int nq = __builtin_amdgcn_readfirstlane((int)pend_q);
+                qhi = __builtin_amdgcn_readfirstlane((int)pend_qn) - 1;
+                whi = qhi >> 6;
+                wd = nq >> 6;
+                mk = uni64(smask[wd]) & (~0ull << (nq & 63));
                 if (wd == whi) mk &= ~0ull >> (63 - (qhi & 63));
+                ask_next();
             }
         };
         advance();
@@ -504,8 +572,8 @@ __device__ __forceinline__ void merge_bulk(SweepLds& L, int S, int row, int t, i
     long long n_iter = 0, n_hbm = 0, n_refill = 0;
 #endif
     // entry idx of (range seg, this row) as (2 v, P = f + v^2, z); from the LDS ring when it is still there, else from HBM
-    auto fetch = [&](int seg, int idx, int sbase, int sslot, bool need) -> float4 {
-        float4 e = ring.get(idx, seg * 64 + row);
+    auto fetch = [&](int rcol, int idx, int sbase, int sslot, bool need) -> float4 {
+        float4 e = ring.get(idx, rcol);
         const bool hb = need && idx < sbase;
         if (__builtin_amdgcn_ballot_w64(hb) != 0ull) {
 #ifdef FDCM_LAB
@@ -546,6 +614,7 @@ __device__ __forceinline__ void merge_bulk(SweepLds& L, int S, int row, int t, i
     const long long lt1 = wall_clock64();
 #endif
     int ms = 0, mi = L.t_cnt[0][row] - 1, ms_lo = 0, ms_base = L.t_base[0][row], ms_slot = L.s_slot0[0];  // the top of the row's stack
+    int ms_rcol = L.r_wave[0] * 64 + row;  // .. and the ring column its top entries are in
     L.t_lo[0][row] = 0;
 #pragma unroll 1
     for (int w = 1; w < S; ++w) {
@@ -554,6 +623,7 @@ __device__ __forceinline__ void merge_bulk(SweepLds& L, int S, int row, int t, i
         float A2v = c0.a2v, Ahq = c0.ahq, Az = c0.az, B2v = 0.f, Bhq = 0.f, Bz = 0.f;
         int wend = 7;  // last window index that is held
         c0 = c1; c1 = c2; c2 = c3; c3 = c4; c4 = c5; c5 = c6;
+        if (S > kSeg) c6 = load_cand(w + 7, 0, false);  // (more than 8 ranges: the junctions past the seventh get theirs on the way)
         int cur = 0, cb = 0;
         bool done = false;
         float zc = 0.f;
@@ -573,7 +643,7 @@ __device__ __forceinline__ void merge_bulk(SweepLds& L, int S, int row, int t, i
             // ---- the incoming entry cur against the 8 entries at the top of the row's stack
             const int idx = mi - t;
             const bool valid = idx >= ms_lo;
-            const float4 e = fetch(ms, max(idx, ms_lo), ms_base, ms_slot, valid && !done);
+            const float4 e = fetch(ms_rcol, max(idx, ms_lo), ms_base, ms_slot, valid && !done);
             // s = ((f[q] + q^2) - f[v] - v^2) / (2q - 2v), left to right in float (imgproc.h:111); pop while s <= z[k]
             const float s = envelope_quotient(chq - e.y, c2v - e.x);
             const bool pop = valid && s <= e.z;
@@ -587,7 +657,7 @@ __device__ __forceinline__ void merge_bulk(SweepLds& L, int S, int row, int t, i
                     else {  // the whole range: on to the range below it
                         L.t_hi[ms][row] = ms_lo - 1;
                         ms = L.t_prev[ms][row];
-                        ms_lo = L.t_lo[ms][row]; ms_base = L.t_base[ms][row]; ms_slot = L.s_slot0[ms];
+                        ms_lo = L.t_lo[ms][row]; ms_base = L.t_base[ms][row]; ms_slot = L.s_slot0[ms]; ms_rcol = L.r_wave[ms] * 64 + row;
                         mi = L.t_hi[ms][row];
                     }
                 } else { mi -= npop; landed = true; }
@@ -635,9 +705,10 @@ __device__ __forceinline__ void merge_bulk(SweepLds& L, int S, int row, int t, i
         L.t_hi[ms][row] = mi;
         L.t_prev[w][row] = ms;
         L.t_lo[w][row] = cur;
-        if (cur >= wbase) ring.put_z(cur, w * 64 + row, zc);
+        const int wrcol = L.r_wave[w] * 64 + row;
+        if (cur >= wbase) ring.put_z(cur, wrcol, zc);
         entr[wslot + cur].z = zc;
-        ms = w; mi = nw - 1; ms_lo = cur; ms_base = wbase; ms_slot = wslot;
+        ms = w; mi = nw - 1; ms_lo = cur; ms_base = wbase; ms_slot = wslot; ms_rcol = wrcol;
     }
     L.t_hi[ms][row] = mi;
 #ifdef FDCM_LAB
@@ -653,6 +724,7 @@ __device__ __forceinline__ void merge_bulk(SweepLds& L, int S, int row, int t, i
 // doubling (3 rounds for 8 entries) instead of entry by entry; the regrouping changes no bit.
 constexpr int kWin = 64;        // owner entries per row kept in LDS for the look-ups
 constexpr int kWinStride = 65;  // (odd: the lanes of a row read neighbouring list positions)
+template <int NR>  // ranges the row's table is laid out for: 8 (no range was taken over) or kMaxR
 __device__ __forceinline__ void walk_batched(SweepLds& L, int W, int S, int part_w, const SweepBuf& B, long chunk, int row, int t, int sh,
                                              unsigned (*l_pk)[kWinStride], float (*l_b)[kWinStride], int (*l_pt)[kWinStride]) {
     const size_t r = (size_t)chunk * 64 + row;
@@ -660,19 +732,19 @@ __device__ __forceinline__ void walk_batched(SweepLds& L, int W, int S, int part
     const EnvEntry* ent = B.ent + r * (size_t)B.eslots;
     // Range table of the row: stream index i lies in range w for i in [o_w, o_{w+1}), at slot i + K_w.
     // (K lives in LDS: the compiler turns a select chain over a register array into an indexed load from scratch memory)
-    int o[kSeg + 1];
+    int o[NR + 1];
     o[0] = 0;
 #pragma unroll
-    for (int w = 0; w < kSeg; ++w) {
+    for (int w = 0; w < NR; ++w) {
         const int lo = w < S ? L.t_lo[w][row] : 0, n = w < S ? max(L.t_hi[w][row] - lo + 1, 0) : 0;
         o[w + 1] = o[w] + n;
-        L.t_K[w][row] = (w < S ? L.s_slot0[w] : 0) + lo - o[w];  // (every lane of a row writes the same value)
+        L.t_K[w][row] = (short)((w < S ? L.s_slot0[w] : 0) + lo - o[w]);  // (every lane of a row writes the same value)
     }
-    const int total = o[kSeg];
+    const int total = o[NR];
     auto slot_of = [&](int i) {
         int w = 0;
 #pragma unroll
-        for (int j = 1; j < kSeg; ++j) w += i >= o[j] ? 1 : 0;  // the last range that starts at or before i (empty ranges in between start there too)
+        for (int j = 1; j < NR; ++j) w += i >= o[j] ? 1 : 0;  // the last range that starts at or before i (empty ranges in between start there too)
         return i + L.t_K[w][row];
     };
     struct WalkEntry { int v; float f; float z; };  // column, f[v], z (the entries in memory hold 2 v and f[v] + v^2)
@@ -895,33 +967,103 @@ __global__ void __launch_bounds__(kNT) k_sweep_balanced(const ColDesc* __restric
         else if (heavy == 2) __builtin_amdgcn_s_setprio(2);
         else if (heavy == 1) __builtin_amdgcn_s_setprio(1);
     }
-    const int S = sweep_ranges(n, B.min_cols);  // ranges of this slice
+    const int S0 = sweep_ranges(n, B.min_cols);  // ranges this slice starts with (one wave each)
     const Ring ring{reinterpret_cast<float*>(pool)};
+    // ---- claim blocks: bsz columns each (8 where the slice is large enough for that, never more than kMaxBlk blocks)
+    // kpr blocks per initial range, of n / nblk columns each (+- 1): ~8 columns where the slice has them, single columns on small
+    // slices, kMaxBlk blocks in all at most; block b begins at the column of rank floor(n b / nblk), so that the
+    // initial ranges hold equal column counts
+    const int per = n / S0;
+    const int kpr = max(1, min(kMaxBlk / kSeg, per >= 16 ? (per + 4) / 8 : per));
+    const int nblk = S0 * kpr;
+    for (int bq = tid; bq <= nblk; bq += kNT) L.blk_q[bq] = (unsigned short)(bq < nblk ? select_column_lane(L.smask, (int)(((long)n * bq) / nblk)) : W);
+    if (tid < kMaxR) { L.s_slot0[tid] = 0x7fffffff; L.r_pos[tid] = tid; }
+    if (tid == 0) {
+        unsigned long long c0 = 0ull, c1 = 0ull;
+        for (int w = 0; w < S0; ++w) { const int bw = w * kpr; if (bw < 64) c0 |= 1ull << bw; else c1 |= 1ull << (bw - 64); }
+        L.claim[0] = c0; L.claim[1] = c1;
+        L.n_ranges = S0;
+    }
+    __syncthreads();
+    {
+        // Wave w < S0 begins with range w at block nblk w / S0 (equal column counts, as far as blocks allow).  A wave without
+        // columns (its stretch ran into the next range, or it never had one) looks for the longest stretch of blocks nobody
+        // has started and begins a new range in its middle, as long as that stretch is worth a stack of its own.
+        EnvEntry* ent_row = B.ent + r * (size_t)B.eslots;
+        int rid = wave, bstart = wave * kpr;
+        bool have = false, run_now = wave < S0;  // have: this wave's ring columns hold a range's top entries
+        int cnt = 0;
+        for (;;) {
+            if (run_now) {
+                run_now = false;
+                have = true;
+                int base, q0;
 #ifdef FDCM_LAB
-    float* fwin = reinterpret_cast<float*>(pool) + 3 * Ring::kPlane;  // [kCW][kNT]: the windows of column values of the local run with lane cursors
-#endif
-    if (wave < S) {
-        const int j0 = (int)(((long)n * wave) / S), j1 = (int)(((long)n * (wave + 1)) / S);  // ranks of the range's columns: [j0, j1), never empty
-        const int q0 = select_column(L.smask, j0), ql = select_column(L.smask, j1 - 1);
-        int cnt, base;
-#ifdef FDCM_LAB
-        if (B.lane_cursors) local_run_cursors(dp, W, L.smask, q0, ql, lane, y, tid, ring, fwin, L.qwin[wave], B.ent + r * (size_t)B.eslots + q0, cnt, base, lab);
-        else
-#endif
-#ifdef FDCM_LAB
-        local_run(dp, W, L.smask, q0, ql, lane, y, tid, ring, B.ent + r * (size_t)B.eslots + q0, cnt, base, lab);
+                local_run(dp, W, L, bstart, nblk, B.steal_min > 0 ? -1 : (wave + 1) * kpr, lane, y, tid, ring, ent_row, cnt, base, q0, lab);
 #else
-        local_run(dp, W, L.smask, q0, ql, lane, y, tid, ring, B.ent + r * (size_t)B.eslots + q0, cnt, base, nullptr);
+                local_run(dp, W, L, bstart, nblk, B.steal_min > 0 ? -1 : (wave + 1) * kpr, lane, y, tid, ring, ent_row, cnt, base, q0, nullptr);
 #endif
-        L.t_cnt[wave][lane] = cnt; L.t_base[wave][lane] = base;
-        if (lane == 0) L.s_slot0[wave] = q0;
+                L.t_cnt[rid][lane] = (short)cnt; L.t_base[rid][lane] = (short)base;
+                if (lane == 0) { L.s_slot0[rid] = q0; L.r_wave[rid] = wave; }
 #ifdef FDCM_LAB
-        if (lab) { const int mc = wave_max(cnt); if (lane == 0) { lab[8] = ql - q0 + 1; lab[9] = j1 - j0; lab[10] = mc; } }
+                if (lab) { const int mc = wave_max(cnt); if (lane == 0) { lab[8] += 1; lab[10] = max((int)lab[10], mc); } }
 #endif
+            }
+            if (B.steal_min <= 0) break;
+            // the longest stretch of unclaimed blocks (wave-uniform scalar scan; the map may change under it: the claim decides)
+            const unsigned long long f0 = ~uni64(L.claim[0]), f1 = ~uni64(L.claim[1]);
+            int best = 0, best_at = 0, run = 0;
+            for (int bb = 0; bb < nblk; ++bb) {
+                const bool fr = (((bb < 64 ? f0 : f1) >> (bb & 63)) & 1ull) != 0ull;
+                run = fr ? run + 1 : 0;
+                if (run > best) { best = run; best_at = bb - run + 1; }
+            }
+            if (best < B.steal_min || best * (n / nblk) < B.steal_cols) break;
+            int id = 0;
+            if (lane == 0) id = atomicAdd(&L.n_ranges, 1);
+            id = __builtin_amdgcn_readfirstlane(id);
+            if (id >= kMaxR) break;                       // (the id is lost: n_ranges only says how many were handed out)
+            const int bs = best_at + best / 2;            // the far half: whoever runs towards it from the left keeps the near one
+            if (!claim_block(L, bs, lane)) continue;      // somebody else got there first (the id stays without a range): look again
+            if (lane == 0 && B.steals) atomicAdd(B.steals, 1);
+            if (have) L.t_base[rid][lane] = (short)cnt;   // this wave's ring columns get a new tenant: the old range is read from memory from now on
+            rid = id; bstart = bs; run_now = true;
+        }
     }
     LAB_STAMP(1);
     __syncthreads();  // every range's stack is in memory, its top entries in the rings
     LAB_STAMP(2);
+    // ---- the ranges in column order: ids beyond the first S0 were handed out as waves ran dry.  The tables are rewritten by
+    // rank (the merge and the walk take the ranges from left to right) -- only when a range was taken over at all.
+    int S = S0;
+    if (__builtin_amdgcn_readfirstlane(L.n_ranges) > S0) {
+        const int nid = min(__builtin_amdgcn_readfirstlane(L.n_ranges), kMaxR);
+        if (tid < kMaxR) {
+            const int mine = tid < nid ? L.s_slot0[tid] : 0x7fffffff;
+            int pos = 0;
+            for (int j = 0; j < nid; ++j) pos += L.s_slot0[j] < mine ? 1 : 0;
+            L.r_pos[tid] = mine == 0x7fffffff ? -1 : pos;
+        }
+        __syncthreads();
+        S = 0;
+        for (int j = 0; j < nid; ++j) S += L.r_pos[j] >= 0 ? 1 : 0;
+        S = __builtin_amdgcn_readfirstlane(S);
+        short pc[2], pb[2];
+        int pp[2], ps[2], pw[2];
+        for (int e = 0; e < 2; ++e) {   // kMaxR * 64 = 2 kNT elements
+            const int i = tid + e * kNT, id = i >> 6, row = i & 63;
+            pp[e] = L.r_pos[id]; pc[e] = L.t_cnt[id][row]; pb[e] = L.t_base[id][row]; ps[e] = L.s_slot0[id]; pw[e] = L.r_wave[id];
+        }
+        __syncthreads();
+        for (int e = 0; e < 2; ++e) {
+            const int i = tid + e * kNT, row = i & 63;
+            if (pp[e] >= 0) {
+                L.t_cnt[pp[e]][row] = pc[e]; L.t_base[pp[e]][row] = pb[e];
+                if (row == 0) { L.s_slot0[pp[e]] = ps[e]; L.r_wave[pp[e]] = pw[e]; }
+            }
+        }
+        __syncthreads();
+    }
     const int g8 = lane >> 3, t8 = lane & 7, sh8 = lane & 56, row8 = wave * 8 + g8;
     {
         EnvEntry* entr = B.ent + ((size_t)chunk * 64 + row8) * (size_t)B.eslots;
@@ -936,8 +1078,12 @@ __global__ void __launch_bounds__(kNT) k_sweep_balanced(const ColDesc* __restric
     LAB_STAMP(4);
     {
         unsigned* w32 = reinterpret_cast<unsigned*>(pool);
-        walk_batched(L, W, S, part_w, B, chunk, row8, t8, sh8, reinterpret_cast<unsigned(*)[kWinStride]>(w32),
-                     reinterpret_cast<float(*)[kWinStride]>(w32 + 64 * kWinStride), reinterpret_cast<int(*)[kWinStride]>(w32 + 2 * 64 * kWinStride));
+        if (S <= kSeg)
+            walk_batched<kSeg>(L, W, S, part_w, B, chunk, row8, t8, sh8, reinterpret_cast<unsigned(*)[kWinStride]>(w32),
+                               reinterpret_cast<float(*)[kWinStride]>(w32 + 64 * kWinStride), reinterpret_cast<int(*)[kWinStride]>(w32 + 2 * 64 * kWinStride));
+        else
+            walk_batched<kMaxR>(L, W, S, part_w, B, chunk, row8, t8, sh8, reinterpret_cast<unsigned(*)[kWinStride]>(w32),
+                                reinterpret_cast<float(*)[kWinStride]>(w32 + 64 * kWinStride), reinterpret_cast<int(*)[kWinStride]>(w32 + 2 * 64 * kWinStride));
     }
     LAB_STAMP(5);
     __syncthreads();  // the chunk's owner lists are in memory
@@ -987,6 +1133,11 @@ void launch_sweep_balanced(hipStream_t st, const void* desc, float* vol, int W, 
     const int part_w = (((W + kSeg - 1) / kSeg) + 3) & ~3;  // fill parts start on a group of 4 columns
     SweepBuf B = B_;
     B.min_cols = sweep_min_cols();
+    // FDCM_SWEEP_STEAL=<blocks> (the tests' switch): a wave out of columns begins a new range in an unclaimed stretch of at least
+    // that many blocks (of 8 columns, fewer on small slices); 0 = never (ranges of equal count only); default kStealMin
+    static const int env_steal = [] { const char* e = getenv("FDCM_SWEEP_STEAL"); const int x = (e && *e) ? atoi(e) : -1; return (x >= 0 && x <= kMaxBlk) ? x : -1; }();
+    B.steal_min = env_steal >= 0 ? env_steal : (B.steal_min < 0 ? kStealMin : B.steal_min);
+    B.steal_cols = env_steal >= 0 ? 0 : kStealCols;  // (the forced threshold counts blocks only: small test images have blocks of one column)
 #ifdef FDCM_LAB
     // FDCM_SWEEP_LOCAL=cursors (lab builds): the local run with a column cursor per lane, for comparisons
     static const int env_cursors = [] { const char* e = getenv("FDCM_SWEEP_LOCAL"); return (e && std::strcmp(e, "cursors") == 0) ? 1 : 0; }();

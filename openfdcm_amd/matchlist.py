@@ -76,7 +76,8 @@ class Match:
             return NotImplemented
         return self._record().tobytes() == other._record().tobytes()
 
-    __hash__ = None
+    def __hash__(self):  # by value, like __eq__ (the reference's Match hashes by identity: sets and dict keys keep working)
+        return hash(self._record().tobytes())
 
     def __repr__(self):
         return f"<Match tmplIdx={self.tmpl_idx}, score={self.score:g}, transform=\n{self.transform}>"

@@ -630,10 +630,15 @@ def test_search_many_templates_generic_work_list(amd):
                                             ({"FDCM_INT_XC": "256"}, 30, 16),
                                             ({"FDCM_INT_XC": "128"}, 30, 17),
                                             ({"FDCM_SEARCH_FLAT": "1"}, 30, 18),
-                                            ({"FDCM_SEARCH_COMPACT2": "1"}, 30, 19)],
+                                            ({"FDCM_SEARCH_COMPACT2": "1"}, 30, 19),
+                                            ({"FDCM_SWEEP_STEAL": "1"}, 80, 20),
+                                            ({"FDCM_SWEEP_STEAL": "1", "FDCM_SWEEP_MINCOLS": "2"}, 60, 21),
+                                            ({"FDCM_SWEEP_STEAL": "1", "FDCM_SWEEP_MINCOLS": "1", "FDCM_SWEEP_ORDER": "1"}, 40, 22),
+                                            ({"FDCM_SWEEP_STEAL": "0"}, 40, 23)],
                          ids=["default", "8-ranges-on-small-slices", "1-column-ranges+launch-order", "literal-one-wave-per-chunk", "host-libm-bins",
                               "integral-252-chain-blocks", "integral-124-chain-blocks", "search-with-64-bit-addresses",
-                              "two-kernel-compaction"])
+                              "two-kernel-compaction", "ranges-taken-over-at-every-chance", "taken-over-on-small-slices",
+                              "taken-over-1-column-blocks+launch-order", "equal-count-ranges-only"])
 def test_randomised_cases(amd, env, cases, seed):
     """Random (scene, depth, distance, padding, coefficient, optimiser, template set) cases: volume and match list
     bit for bit (tools/fuzz_parity.py).  The variants force the paths of the L2 sweep that the default sizes do not
@@ -642,7 +647,8 @@ def test_randomised_cases(amd, env, cases, seed):
     one-wave-per-chunk kernel that sizes above the exact-integer bound take; the orientation bins of the aligned template lines from the host
     libm (the path a host whose atanf differs from the device restatement takes); the wide-block forms of the steep
     line integral that only large volumes select; the search with 64-bit flat addresses (what volumes of 4 GB and more take);
-    the two-kernel form of the positional compaction (what searches of more than 65 536 candidates take)."""
+    the two-kernel form of the positional compaction (what searches of more than 65 536 candidates take); the sweep's dynamic cuts
+    forced at every chance (also on slices of few columns and with blocks of one column) and forbidden."""
     import os
     import subprocess
     import sys
@@ -650,6 +656,14 @@ def test_randomised_cases(amd, env, cases, seed):
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), str(cases), str(seed)],
                          capture_output=True, text=True, timeout=600, env={**os.environ, **env})
     assert out.returncode == 0 and f"{cases} random cases identical" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+    # the dynamic cuts of the L2 sweep (a wave out of columns begins a new range in what nobody has started): the variants that
+    # force them at every chance must have taken ranges over, the one that forbids them none
+    import re
+    taken = int(re.search(r"(\d+) ranges taken over", out.stdout).group(1))
+    if env.get("FDCM_SWEEP_STEAL") == "1" and env.get("FDCM_SWEEP_MINCOLS") != "1":  # (ranges of one column leave nothing to take over)
+        assert taken > cases, out.stdout[-500:]
+    if env.get("FDCM_SWEEP_STEAL") == "0" or env.get("FDCM_L2_SWEEP") == "literal":
+        assert taken == 0, out.stdout[-500:]
 
 
 @pytest.mark.parametrize("env", [{}, {"FDCM_SWEEP_ORDER": "1"}], ids=["default", "launch-order-from-history"])

@@ -95,6 +95,7 @@ def test_standalone_match_and_plain_lists_still_work():
     pen = api.penalize(api.DefaultPenalty(), ms, [2.0, 4.0, 8.0, 16.0])
     assert [m.score for m in pen] == [1.5, 0.125, 0.25, 0.015625] and ms[0].score == 3.0
     assert Match(1, 2.0, np.eye(2, 3)) == Match(1, 2.0, np.eye(2, 3)) and Match(1, 2.0, np.eye(2, 3)) != Match(1, 2.5, np.eye(2, 3))
+    assert len({Match(1, 2.0, np.eye(2, 3)), Match(1, 2.0, np.eye(2, 3)), Match(2, 2.0, np.eye(2, 3))}) == 2   # usable in sets / as keys
 
     class Duck:                       # anything with the three attributes, as before
         def __init__(self, i, s): self.tmpl_idx, self.score, self.transform = i, s, [[1, 0, 0], [0, 1, 0]]

@@ -13,6 +13,8 @@ n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed0)
 t0 = time.time()
+steals = 0  # ranges the L2 sweep's waves took over from slower ones (dynamic cuts), summed over the cases
+import ctypes
 for case in range(n_cases):
     S = int(rng.choice([33, 64, 97, 150, 256, 300, 511, 640]))
     n_lines = int(rng.integers(2, 120))
@@ -40,5 +42,14 @@ for case in range(n_cases):
     got = search_raw(dev, DeviceTemplates(tmpls), scene, maxT, maxS, kind, batch)
     want = O.search(orc, tmpls, scene, maxT, maxS, kind=kind, batch=batch, nthreads=8).astype(_capi.MATCH_DTYPE)
     assert got.tobytes() == want.tobytes(), ("matches", case, S, n_lines, depth, dist, kind, batch, maxT, maxS, len(got), len(want))
+    if rng.random() < 0.5:  # the handle rebuilt with another scene of another size (the ranges are cut anew by whoever runs dry first)
+        scene2 = np.array(synthetic.scene(int(rng.choice([64, 200, 333])), int(rng.integers(2, 80)), int(rng.integers(1, 1 << 30))), dtype=np.float32)
+        dev.rebuild(scene2)
+        orc2 = O.build(scene2, depth=depth, coeff=coeff, padding=padding, distance=dist, nthreads=8)
+        a, b = dev.volume(), orc2.volume()
+        assert a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32)), ("rebuilt volume", case, depth, dist, padding)
+    c = ctypes.c_int64()
+    _capi.check(_capi.lib().fdcm_selftest_sweep_steals(dev._h, ctypes.byref(c)))
+    steals += c.value
     dev.close()
-print(f"{n_cases} random cases identical to the oracle (seed {seed0}), {time.time() - t0:.0f} s")
+print(f"{n_cases} random cases identical to the oracle (seed {seed0}), {steals} ranges taken over, {time.time() - t0:.0f} s")
