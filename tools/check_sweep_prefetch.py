@@ -4,7 +4,8 @@
 local_run issues the next column's `s_load_dwordx4` from inline assembly WITHOUT a wait: the data lands behind the pop
 loop's own `s_waitcnt lgkmcnt(0)`.  The compiler does not know that those four SGPRs are in flight, so nothing in the
 language stops it from copying or spilling them before the wait.  This script reads the code the compiler actually
-produced: in every kernel of libfdcm_hip.so that contains such a load, from an `s_load_dwordx4 s[a:b]` that is not
+produced: in every kernel of libfdcm_hip.so that contains such a load, from an `s_load_dwordx4 s[a:b]` (other than the
+compiler's own loads of the kernel arguments, base s[0:1]) that is not
 followed by its own wait up to the next `s_waitcnt` that covers lgkmcnt(0), no instruction may name a register of
 s[a:b].  Exit 0 and one line per kernel when that holds; non-zero with the offending lines otherwise.
 
@@ -78,6 +79,9 @@ def scan(kernel, lines):
     for i, ins in enumerate(lines):
         if not ins.startswith("s_load_dwordx4"):
             continue
+        ops = [o.strip() for o in ins[len("s_load_dwordx4"):].split(",")]
+        if len(ops) >= 2 and ops[1] == "s[0:1]":
+            continue  # the compiler's own loads of the kernel arguments (base = the kernarg pointer): it tracks those itself
         dst = sregs(ins.split(",")[0])
         if i + 1 < len(lines) and covers_lgkm0(lines[i + 1]):
             continue  # waited for on the spot
