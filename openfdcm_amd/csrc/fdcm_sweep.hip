@@ -14,13 +14,22 @@
 //   => the owner of every pixel in the reference's run is the EXACT owner: the seeded column u minimising
 //      f[u] + (q - u)^2 over the integers, the smallest u on a tie.  The same holds for the reference's construction run on
 //      ANY subset of the columns that contains those owners.
-// So a row may be cut anywhere: S waves run the literal construction on S column ranges of equal seeded-column count,
-// each on its own stack (bottom = its first column, z = -inf), and the stacks are then merged from left to right by
+// So a row may be cut anywhere -- and the cuts need not be known in advance.  The waves start on S column ranges of equal
+// seeded-column count; columns are handed out in blocks of ~8 through a bit map in LDS, a wave goes on through the blocks
+// behind its own until it meets one that has an owner, and a wave that has run dry begins a NEW range in the middle of the
+// longest stretch nobody has started (up to kMaxR = 16 ranges per row): the slowest wave of a workgroup -- the one whose
+// columns make some row pop a lot, 3 x the mean on unlucky scenes -- is relieved of the far half of what it has left.
+// Each range runs the literal construction on its own stack (bottom = its first column, z = -inf), the ranges are put in
+// column order, and the stacks are then merged from left to right by
 // landing the next range's entries on the accumulated stack (pop while s <= z, as the reference would) until one of
 // them stays on its local predecessor -- which IS the reference's construction on the union of the local stacks, a set
 // that contains every pixel owner.  No junction search, no speculation, no redo; the longest wave of a block holds
 // n / S columns whatever the scene looks like.  The fill with the in-place read-back (:126-127) is unchanged:
 // the owner list (first pixel, column, addend) of a row, addend = f[v] or the already written g[v].
+//
+// (Dynamic cuts shorten the heaviest workgroup's chain and add junctions: run_build turns them on where the kernel lasts as
+// long as its slowest workgroup -- all workgroups resident, one blocking build on the GPU -- and leaves the ranges of equal
+// count where workgroups queue for the CUs or the frames of a pipeline share them.)
 //
 // One workgroup per (slice, 64-row chunk), kSeg waves, lane = row:
 //   local run   wave w: the literal construction over its columns; stack = top entry in registers + a ring of kRing
@@ -969,7 +978,7 @@ __global__ void __launch_bounds__(kNT) k_sweep_balanced(const ColDesc* __restric
     }
     const int S0 = sweep_ranges(n, B.min_cols);  // ranges this slice starts with (one wave each)
     const Ring ring{reinterpret_cast<float*>(pool)};
-    // ---- claim blocks: bsz columns each (8 where the slice is large enough for that, never more than kMaxBlk blocks)
+    // ---- claim blocks
     // kpr blocks per initial range, of n / nblk columns each (+- 1): ~8 columns where the slice has them, single columns on small
     // slices, kMaxBlk blocks in all at most; block b begins at the column of rank floor(n b / nblk), so that the
     // initial ranges hold equal column counts
