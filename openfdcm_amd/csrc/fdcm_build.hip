@@ -738,7 +738,8 @@ void run_build(fdcm_featuremap* fm, const BuildPlan& plan, int stop_after, bool 
         // (all workgroups resident at once, the GPU to this handle), not where workgroups queue for the CUs or frames of a
         // pipeline share them (config 2: one blocking build 0.354 -> 0.333 ms over four scenes; four frames in flight 69.7 ->
         // 68.4 M matches/s; config 3: 0.76 -> 0.81 ms).  FDCM_SWEEP_STEAL=<blocks> forces a threshold (0: never) for the tests.
-        sb.steal_min = (!fm->shares_gpu && nchunks <= 2L * device_cus(fm->device)) ? -1 : 0;  // -1: the kernel's default threshold
+        sb.steal_min = -1;  // the kernel's default threshold
+        sb.steal_heavy_only = (!fm->shares_gpu && nchunks <= 2L * device_cus(fm->device)) ? 0 : 1;
         sb.steals = (int*)(sp + o_steals);
         if (!reserve_only) {
             if (fm->sweep_steals != sb.steals) FDCM_HIP(hipMemsetAsync(sp + o_steals, 0, 256, st));  // a new scratch (or shape): count from 0

@@ -20,6 +20,7 @@ struct SweepBuf {
     int min_cols;                         // seeded columns a range holds at least (set by the launcher)
     int steal_min;                        // a wave out of columns starts a new range in a stretch of at least this many unclaimed blocks
                                           // (0: never, ranges of equal count only; < 0: the launcher's default; FDCM_SWEEP_STEAL overrides both)
+    int steal_heavy_only;                 // 1: only the heaviest workgroups (launch rank / seeded columns) cut dynamically
     int steal_cols;                       // .. that holds this many columns at least
     int* steals;                          // [0]: ranges taken over so far (all launches of the handle), or null
 #ifdef FDCM_LAB

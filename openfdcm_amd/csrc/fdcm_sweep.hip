@@ -970,8 +970,9 @@ __global__ void __launch_bounds__(kNT) k_sweep_balanced(const ColDesc* __restric
     // workgroup shares its CU's SIMDs with a lighter one: the heavy ones get the issue slots first.  Rank in the launch order
     // when there is one (longest chunks of the previous build first), the slice's seeded columns otherwise.  (Config 2: 0.190 -
     // 0.193 ms against 0.196 - 0.198 without, three alternating pairs on one box; config 3: no difference.)
+    int heavy;
     {
-        const int heavy = B.order ? (blockIdx.x < 96u ? 3 : blockIdx.x < 224u ? 2 : blockIdx.x < 512u ? 1 : 0) : min(3, 4 * n / max(W, 1));
+        heavy = B.order ? (blockIdx.x < 96u ? 3 : blockIdx.x < 224u ? 2 : blockIdx.x < 512u ? 1 : 0) : min(3, 4 * n / max(W, 1));
         if (heavy == 3) __builtin_amdgcn_s_setprio(3);
         else if (heavy == 2) __builtin_amdgcn_s_setprio(2);
         else if (heavy == 1) __builtin_amdgcn_s_setprio(1);
@@ -998,6 +999,9 @@ __global__ void __launch_bounds__(kNT) k_sweep_balanced(const ColDesc* __restric
         // Wave w < S0 begins with range w at block nblk w / S0 (equal column counts, as far as blocks allow).  A wave without
         // columns (its stretch ran into the next range, or it never had one) looks for the longest stretch of blocks nobody
         // has started and begins a new range in its middle, as long as that stretch is worth a stack of its own.
+        // (where workgroups queue for the CUs or share them with other frames, only the heaviest ones cut dynamically: theirs are
+        // the chains the kernel ends with, and the junctions a new range adds are work the others would only pay for)
+        const bool dyn = B.steal_min > 0 && (B.steal_heavy_only == 0 || heavy >= 3);
         EnvEntry* ent_row = B.ent + r * (size_t)B.eslots;
         int rid = wave, bstart = wave * kpr;
         bool have = false, run_now = wave < S0;  // have: this wave's ring columns hold a range's top entries
@@ -1008,9 +1012,9 @@ __global__ void __launch_bounds__(kNT) k_sweep_balanced(const ColDesc* __restric
                 have = true;
                 int base, q0;
 #ifdef FDCM_LAB
-                local_run(dp, W, L, bstart, nblk, B.steal_min > 0 ? -1 : (wave + 1) * kpr, lane, y, tid, ring, ent_row, cnt, base, q0, lab);
+                local_run(dp, W, L, bstart, nblk, dyn ? -1 : (wave + 1) * kpr, lane, y, tid, ring, ent_row, cnt, base, q0, lab);
 #else
-                local_run(dp, W, L, bstart, nblk, B.steal_min > 0 ? -1 : (wave + 1) * kpr, lane, y, tid, ring, ent_row, cnt, base, q0, nullptr);
+                local_run(dp, W, L, bstart, nblk, dyn ? -1 : (wave + 1) * kpr, lane, y, tid, ring, ent_row, cnt, base, q0, nullptr);
 #endif
                 L.t_cnt[rid][lane] = (short)cnt; L.t_base[rid][lane] = (short)base;
                 if (lane == 0) { L.s_slot0[rid] = q0; L.r_wave[rid] = wave; }
@@ -1018,7 +1022,7 @@ __global__ void __launch_bounds__(kNT) k_sweep_balanced(const ColDesc* __restric
                 if (lab) { const int mc = wave_max(cnt); if (lane == 0) { lab[8] += 1; lab[10] = max((int)lab[10], mc); } }
 #endif
             }
-            if (B.steal_min <= 0) break;
+            if (!dyn) break;
             // the longest stretch of unclaimed blocks (wave-uniform scalar scan; the map may change under it: the claim decides)
             const unsigned long long f0 = ~uni64(L.claim[0]), f1 = ~uni64(L.claim[1]);
             int best = 0, best_at = 0, run = 0;
@@ -1146,6 +1150,9 @@ void launch_sweep_balanced(hipStream_t st, const void* desc, float* vol, int W, 
     // that many blocks (of 8 columns, fewer on small slices); 0 = never (ranges of equal count only); default kStealMin
     static const int env_steal = [] { const char* e = getenv("FDCM_SWEEP_STEAL"); const int x = (e && *e) ? atoi(e) : -1; return (x >= 0 && x <= kMaxBlk) ? x : -1; }();
     B.steal_min = env_steal >= 0 ? env_steal : (B.steal_min < 0 ? kStealMin : B.steal_min);
+    static const int env_heavy = [] { const char* e = getenv("FDCM_SWEEP_STEAL_HEAVY"); return (e && *e) ? atoi(e) : -1; }();  // measurement: 0 all workgroups, 1 the heaviest only
+    if (env_heavy >= 0) B.steal_heavy_only = env_heavy;
+    else if (env_steal >= 0) B.steal_heavy_only = 0;
     B.steal_cols = env_steal >= 0 ? 0 : kStealCols;  // (the forced threshold counts blocks only: small test images have blocks of one column)
 #ifdef FDCM_LAB
     // FDCM_SWEEP_LOCAL=cursors (lab builds): the local run with a column cursor per lane, for comparisons
