@@ -326,13 +326,19 @@ def main():
             blocking_frame(cycle=False)
             if i >= 3:
                 same.append(fm.build_timing()["span_ms"])
+        fm.stage_timing(1)
+        same_pass2 = []
+        for i in range(max(3, args.single_frames // 3)):  # .. and its dominant kernel's time (an event between the stages)
+            blocking_frame(cycle=False)
+            same_pass2.append(fm.build_timing()["pass2_ms"])
         fm.stage_timing(False)  # the frame as a caller runs it: no events at all, wall clock around the two calls
         for _ in range(args.single_frames + 3):
             t1 = time.perf_counter()
             blocking_frame()
             wall.append(time.perf_counter() - t1)
         single = {"stage_ms": {k: float(np.mean(v)) for k, v in st.items()}, "search_kernel_ms": float(np.mean(sk)),
-                  "span_ms": float(np.mean(spans)), "same_scene_span_ms": float(np.mean(same)), "build_total_ms": float(np.mean(totals)),
+                  "span_ms": float(np.mean(spans)), "same_scene_span_ms": float(np.mean(same)), "same_scene_pass2_ms": float(np.mean(same_pass2)),
+                  "build_total_ms": float(np.mean(totals)),
                   "frame_ms": float(np.mean(wall[3:])) * 1e3}
         fm.close()
 
@@ -445,6 +451,14 @@ def main():
                                            "feature map's own stream: one before the build's first kernel and one behind its last; the stage "
                                            f"table comes from {args.single_frames} more frames with an event between the stages, which cost 3 - 5 us "
                                            f"each (their sum: {stage_sum:.4f} ms)",
+                               # the kernel the build's time hangs on, by itself (its 3 V are pass 1's V written + pass 2's V read and V written)
+                               "dominant_kernel": {"kernel": STAGE_KERNELS["pass2_ms"], "algorithmic_bytes_per_launch": STAGE_BYTES_V["pass2_ms"] * V,
+                                                   "avg_launch_ms": s_ms["pass2_ms"],
+                                                   "frac": STAGE_BYTES_V["pass2_ms"] * V / (s_ms["pass2_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS if s_ms["pass2_ms"] > 0 else None,
+                                                   "same_scene_ms": single["same_scene_pass2_ms"],
+                                                   "same_scene_frac": STAGE_BYTES_V["pass2_ms"] * V / (single["same_scene_pass2_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS if single["same_scene_pass2_ms"] > 0 else None,
+                                                   "note": f"averaged over the {n_scenes} scenes cycled; same_scene = scene seed 1 rebuilt over and over (what rounds 1 - 5 reported); "
+                                                           "its time is its slowest workgroup's, which is the scene's (profiles/NOTES.md section 12)"},
                                "stages": table}
             reads = 8.0 * acc["evaluations"] * cfg["n"]
             s_lo, s_hi, s_src = pmc_search_traffic(args.config)

@@ -76,6 +76,9 @@ class Match:
             return NotImplemented
         return self._record().tobytes() == other._record().tobytes()
 
+    def __reduce__(self):  # by value: a pickled or deep-copied Match does not drag its list's records along
+        return (Match, (self.tmpl_idx, self.score, np.array(self.transform, dtype=np.float32, copy=True)))
+
     def __hash__(self):  # by value, like __eq__ (the reference's Match hashes by identity: sets and dict keys keep working)
         return hash(self._record().tobytes())
 
@@ -184,6 +187,14 @@ class MatchList(MutableSequence):
     def copy(self):
         return self[:]
 
+    def __reduce__(self):  # pickle / deepcopy by value: one record array (the column views of the store are rebuilt, not pickled)
+        if self._items is None:
+            return (MatchList, (np.array(self._s.rec, dtype=MATCH_DTYPE, copy=True, order="C"),))
+        return (_matchlist_of_items, (list(self._items),))
+
+    def __copy__(self):  # copy.copy: a new list object over the same elements, like copy.copy(list)
+        return self[:]
+
     def __repr__(self):
         n = len(self)
         if n <= 6:
@@ -223,3 +234,7 @@ class MatchList(MutableSequence):
     def sort(self, *, key=None, reverse=False):
         self._materialise().sort(key=key, reverse=reverse)
 
+
+
+def _matchlist_of_items(items):
+    return MatchList._of_items(items)

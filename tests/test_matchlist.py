@@ -168,3 +168,24 @@ def test_sort_and_penalize_equal_the_reference_order_with_ties():
     nan = make_records(400, seed=2)
     nan["score"][5] = np.nan                  # std::sort's answer, whatever it is
     assert records_of(api.sort_matches(MatchList(nan.copy()))).tobytes() == O.sort_matches(nan).tobytes()
+
+
+def test_copy_and_pickle():
+    """A caller that stores results (copy, deepcopy, pickle) gets independent data, as with list[Match]."""
+    import copy
+    import pickle
+    ml = MatchList(make_records(5, seed=4))
+    for clone in (copy.deepcopy(ml), pickle.loads(pickle.dumps(ml))):
+        assert isinstance(clone, MatchList) and clone == ml
+        clone[0].score = -1.0
+        assert ml[0].score != -1.0 and clone.records()["score"][0] == np.float32(-1.0)   # the clone's elements still write through
+    sh = copy.copy(ml)                 # a shallow copy shares the elements, like copy.copy(list)
+    sh[1].score = -2.0
+    assert ml[1].score == -2.0
+    m = pickle.loads(pickle.dumps(ml[2]))
+    assert isinstance(m, Match) and m == ml[2]
+    m.score = 5.0
+    assert ml[2].score != 5.0
+    restructured = MatchList(make_records(4, seed=6))
+    restructured.reverse()
+    assert pickle.loads(pickle.dumps(restructured)) == restructured
