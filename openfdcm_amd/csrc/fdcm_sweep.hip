@@ -580,21 +580,6 @@ __device__ __forceinline__ void merge_bulk(SweepLds& L, int S, int row, int t, i
 #ifdef FDCM_LAB
     long long n_iter = 0, n_hbm = 0, n_refill = 0;
 #endif
-    // entry idx of (range seg, this row) as (2 v, P = f + v^2, z); from the LDS ring when it is still there, else from HBM
-    auto fetch = [&](int rcol, int idx, int sbase, int sslot, bool need) -> float4 {
-        float4 e = ring.get(idx, rcol);
-        const bool hb = need && idx < sbase;
-        if (__builtin_amdgcn_ballot_w64(hb) != 0ull) {
-#ifdef FDCM_LAB
-            ++n_hbm;
-#endif
-            const EnvEntry h = entr[sslot + idx];
-            float hv, hf, hz;
-            asm volatile("v_mov_b32 %0, %3\n\tv_mov_b32 %1, %4\n\tv_mov_b32 %2, %5" : "=&v"(hv), "=&v"(hf), "=&v"(hz) : "v"(h.v2), "v"(h.P), "v"(h.z));
-            if (hb) e = make_float4(hv, hf, hz, 0.f);
-        }
-        return e;
-    };
     // The first 8 incoming entries of every junction are fetched together before the first one is needed (one trip to
     // memory for all of them; the sets rotate through named registers): lane t holds entry t of the range as
     // (2 v, f + v^2, local z).  (Entries 8 .. 15 only come with a refill: rows scatter over memory, and the fetches of a
@@ -650,14 +635,33 @@ __device__ __forceinline__ void merge_bulk(SweepLds& L, int S, int row, int t, i
             firstit = false;
 #endif
             // ---- the incoming entry cur against the 8 entries at the top of the row's stack
+            // (lane t looks at entry mi - t: (2 v, P = f + v^2, z) from the LDS ring while it is still there.  The entries below
+            // the ring -- the deeper lanes, after earlier pops -- are in memory: they are only fetched when the run of pops gets
+            // as far as the first of them, since the reference stops at the first entry that does not pop.  Round 5 fetched them
+            // whenever a lane looked below the ring: 40 of a deep-stack workgroup's 50 merge steps made a trip to memory.)
             const int idx = mi - t;
             const bool valid = idx >= ms_lo;
-            const float4 e = fetch(ms_rcol, max(idx, ms_lo), ms_base, ms_slot, valid && !done);
+            const int ci = max(idx, ms_lo);
+            float4 e = ring.get(ci, ms_rcol);
+            const bool deep = valid && !done && ci < ms_base;
             // s = ((f[q] + q^2) - f[v] - v^2) / (2q - 2v), left to right in float (imgproc.h:111); pop while s <= z[k]
-            const float s = envelope_quotient(chq - e.y, c2v - e.x);
-            const bool pop = valid && s <= e.z;
-            const unsigned m8 = (unsigned)(__builtin_amdgcn_ballot_w64(pop) >> sh) & 0xffu;
-            const int npop = __builtin_ctz(~m8);  // leading pops, 0..8
+            float s = envelope_quotient(chq - e.y, c2v - e.x);
+            bool pop = valid && !deep && s <= e.z;
+            unsigned m8 = (unsigned)(__builtin_amdgcn_ballot_w64(pop) >> sh) & 0xffu;
+            int npop = __builtin_ctz(~m8);  // leading pops, 0..8
+            if (__builtin_amdgcn_ballot_w64(deep && npop == t) != 0ull) {  // some row's pops reach below its ring: one trip for all deep lanes
+#ifdef FDCM_LAB
+                ++n_hbm;
+#endif
+                const EnvEntry h = entr[ms_slot + ci];
+                float hv, hf, hz;
+                asm volatile("v_mov_b32 %0, %3\n\tv_mov_b32 %1, %4\n\tv_mov_b32 %2, %5" : "=&v"(hv), "=&v"(hf), "=&v"(hz) : "v"(h.v2), "v"(h.P), "v"(h.z));
+                if (deep) e = make_float4(hv, hf, hz, 0.f);
+                s = envelope_quotient(chq - e.y, c2v - e.x);
+                pop = valid && s <= e.z;
+                m8 = (unsigned)(__builtin_amdgcn_ballot_w64(pop) >> sh) & 0xffu;
+                npop = __builtin_ctz(~m8);
+            }
             const int nvalid = min(8, mi - ms_lo + 1);
             bool landed = false;
             if (!done) {
