@@ -24,7 +24,6 @@ struct SweepBuf {
     int steal_cols;                       // .. that holds this many columns at least
     int* steals;                          // [0]: ranges taken over so far (all launches of the handle), or null
 #ifdef FDCM_LAB
-    int lane_cursors;                     // lab builds: the local run with a column cursor per lane (FDCM_SWEEP_LOCAL=cursors)
     long long* lab;                       // lab builds (make LAB=1): 16 clock stamps / counters per (chunk, wave), or null
 #endif
 };

@@ -55,12 +55,6 @@ static constexpr int kRing = 8;      // stack entries per (row, range) below the
 static constexpr int kRE = 10;       // owner entries per row and round of the fill (three words each in LDS)
 [[maybe_unused]] static constexpr int kLabN = 24;     // lab builds: 64-bit words per (chunk, wave) record
 static constexpr int kMinCols = 16;  // a range holds at least this many seeded columns (fewer ranges on small slices); FDCM_SWEEP_MINCOLS
-[[maybe_unused]] static constexpr int kCW = 8;        // lab: columns in a lane's window of the local run with lane cursors (a lane runs at most this far ahead of its wave's slowest)
-#ifdef FDCM_LAB
-static constexpr int kLabWin = kCW;
-#else
-static constexpr int kLabWin = 0;
-#endif
 
 // The LDS ring of stack entries, three planes of consecutive dwords: entry i of workgroup lane c is
 // (2 v, P = f + v^2, z) = plane[0..2][i & (kRing - 1)][c].  In the local run a lane reads and writes its own column c (bank = c mod 32
@@ -104,9 +98,6 @@ struct SweepLds {
     int n_ranges;                    // range ids handed out so far
     int s_lcount[64];                // owner entries per row
     int s_pi[kSeg][64];              // [p - 1][row]: list index that owns the first pixel of fill part p
-#ifdef FDCM_LAB
-    float qwin[kSeg][kCW];           // local run with lane cursors: 2 q of the columns in a wave's window
-#endif
 };
 
 // position of the t-th set bit (t from 0) of the mask words; wave-uniform
@@ -370,195 +361,9 @@ __device__ __forceinline__ void local_run(const uint4* __restrict__ dp, int W, S
     cnt_out = cnt; base_out = base;
 }
 
-#ifdef FDCM_LAB
-// ---- (lab builds only: FDCM_SWEEP_LOCAL=cursors) the same construction with a column cursor per lane.  Measured in round 5
-// and not shipped: the local run is bound by the instructions a wave issues (tools/valu_issue_bench.hip: 2 - 3 cycles of its
-// SIMD per vector instruction with four waves on it, ~5 per instruction for a wave by itself), and a pass with its own
-// cursor takes ~45 instructions where the shared cursor's takes 20: config 2 0.22 ms against 0.195, although the longest wave
-// makes 201 passes instead of 482 (profiles/NOTES.md section 11).  In local_run the wave shares the cursor: a column costs the
-// wave as many passes as its slowest row needs (a heavy wave of BASELINE config 2: 4.8 per column where a row makes 2).
-// Here every lane walks the range's columns by itself, one test per pass: pop the top, or push the column and move on.
-// The wave stages the columns -- every lane's P = f + q^2 into the lane's own LDS window of kCW columns, the columns' 2 q
-// into a table of the wave -- one at a time, as soon as the slowest lane has left the window slot: a lane runs at most kCW
-// columns ahead of the slowest (tools/sim/cursor_sim.cpp: the longest wave of config 2 makes 205 - 232 passes instead of
-// 482).  A pass is one statement of assembly: the entry below the top and the next column are read from LDS at its start and
-// waited for behind the quotient, so nothing is in flight between two passes; its LDS traffic is conflict-free.
-__device__ __forceinline__ void local_run_cursors(const uint4* __restrict__ dp, int W, const unsigned long long* smask, int q0, int ql, int lane, int y, int tid,
-                                                  const Ring ring, float* __restrict__ fwin, float* __restrict__ qwin, EnvEntry* __restrict__ ent,
-                                                  int& cnt_out, int& base_out, long long* lab) {
-#ifdef FDCM_LAB
-    long long n_pass = 0, n_stage = 0, n_flag = 0, cyc_pass = 0, cyc_stage = 0;
-    const long long cyc0 = __builtin_amdgcn_s_memtime();
-#endif
-    const float inf = f_inf();
-    const uint4 db = dp[q0];
-    float tvx2, tP, tz = -inf;  // the top entry
-    {
-        const float vf = (float)q0;
-        tvx2 = vf + vf;
-        tP = column_value_sq_seeded(((unsigned long long)db.y << 32) | db.x, (int)db.z, (int)db.w, lane, y) + vf * vf;
-    }
-    int cnt = 0, base = 0;  // entries below the top: [base, cnt) in the LDS ring, [0, base) in HBM
-    const int qlo = q0 + 1, qhi = ql;
-    if (qlo <= qhi) {
-        float* fw = fwin + tid;  // column j of the range: fw[(j & (kCW - 1)) * kNT]
-        const unsigned lb = (unsigned)(size_t)(ring.p + tid), fwb = (unsigned)(size_t)fw, qwb = (unsigned)(size_t)qwin;
-        // the range's seeded columns, word by word (columns without a seed in the slice never own a pixel: skipped)
-        const int whi = qhi >> 6;
-        int wd = qlo >> 6;
-        unsigned long long mk = uni64(smask[wd]) & (~0ull << (qlo & 63));
-        if (wd == whi) mk &= ~0ull >> (63 - (qhi & 63));
-        while (mk == 0ull && wd < whi) {
-            ++wd;
-            mk = uni64(smask[wd]);
-            if (wd == whi) mk &= ~0ull >> (63 - (qhi & 63));
-        }
-        int staged = 0;              // columns of the range staged so far (wave-uniform)
-        int c = 0;                   // this lane's cursor: it is testing column c of the range (waiting for it when c == staged)
-        float hq = 0.f, twoq = 0.f;  // P and 2 q of column c
-        int flag = 0;                // the last pass left a lane with a full ring, or an empty one above the stack's bottom
-        for (;;) {
-            // ---- stage the next column while the slot is free: no lane may still have to read column staged - kCW from it
-            while (mk != 0ull && __builtin_amdgcn_ballot_w64(c < staged - kCW) == 0ull) {
-#ifdef FDCM_LAB
-                const long long cs0 = __builtin_amdgcn_s_memtime();
-                ++n_stage;
-#endif
-                const int j = __ffsll((long long)mk) - 1;
-                mk &= mk - 1ull;
-                const int q = wd * 64 + j;
-                // the column's descriptor: the same 16 bytes for every lane, so a scalar load into SGPRs (a vector load would
-                // wait for every eviction store in flight: loads and stores share the counter)
-                u32x4 dq;
-                asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dq) : "s"(dp + q) : "memory");
-                const float fq = column_value_sq_seeded(((unsigned long long)dq.y << 32) | dq.x, (int)dq.z, (int)dq.w, lane, y);
-                const float qf = (float)q;
-                const float P = fq + qf * qf;  // q * q rounds like the reference's float(long(q * q))
-                const int slot = staged & (kCW - 1);
-                fw[slot * kNT] = P;
-                if (lane == 0) qwin[slot] = qf + qf;
-                if (c == staged) { hq = P; twoq = qf + qf; }  // lanes that were waiting for this column
-                ++staged;
-                while (mk == 0ull && wd < whi) {
-                    ++wd;
-                    mk = uni64(smask[wd]);
-                    if (wd == whi) mk &= ~0ull >> (63 - (qhi & 63));
-                }
-#ifdef FDCM_LAB
-                cyc_stage += __builtin_amdgcn_s_memtime() - cs0;
-#endif
-            }
-            if (__builtin_amdgcn_ballot_w64(c < staged) == 0ull) break;  // every lane is through (a waiting lane would have had its column staged)
-            // ---- the ring between passes.  A pass may always push (a free slot) and always pop (the entry below the top is in
-            // the ring): when the last pass left some lane with a full ring, or an empty one above spilled entries, every lane
-            // that is close to either state is served with it -- rings with 7 or 8 entries send their oldest to memory until 5 are
-            // left (stores: nothing waits for them), rings with at most one entry above spilled ones get four back (the wave
-            // waits for those once: the lanes of a wave reach such points within a few passes of each other).
-            if (flag) {  // wave-uniform
-#ifdef FDCM_LAB
-                ++n_flag;
-#endif
-                const int d = cnt - base;
-                if (__builtin_amdgcn_ballot_w64(d >= 7) != 0ull) {
-#pragma unroll
-                    for (int e = 0; e < 3; ++e)
-                        if (d - e > 5) ent[base + e] = to_mem(ring.get(base + e, tid));
-                    if (d >= 7) base += d - 5;
-                }
-                const bool rf = d <= 1 && base > 0;
-                if (__builtin_amdgcn_ballot_w64(rf) != 0ull) {
-                    if (rf) {
-                        // all four are written (at most one slot is taken; entries below 0 land in free slots): no load stays pending
-                        const EnvEntry e0 = ent[max(base - 1, 0)], e1 = ent[max(base - 2, 0)], e2 = ent[max(base - 3, 0)], e3 = ent[max(base - 4, 0)];
-                        ring.put(base - 1, tid, e0.v2, e0.P, e0.z);
-                        ring.put(base - 2, tid, e1.v2, e1.P, e1.z);
-                        ring.put(base - 3, tid, e2.v2, e2.P, e2.z);
-                        ring.put(base - 4, tid, e3.v2, e3.P, e3.z);
-                        base = max(base - 4, 0);
-                    }
-                }
-            }
-            // ---- one pass: s = ((f[q] + q^2) - f[v] - v^2) / (2q - 2v) (imgproc.h:111) by envelope_quotient's four instructions;
-            // pop (imgproc.h:113-115) while s <= z[k] (the bottom's z is -inf: never popped), else push (:117-120) and move on.
-            // flag = 1 when a lane's ring is full or empty (above the bottom) afterwards.
-#ifdef FDCM_LAB
-            const long long cp0 = __builtin_amdgcn_s_memtime();
-            ++n_pass;
-#endif
-            {
-                float s, lv, lp, lz, nh, nq, qd, qn, qr, qe;
-                unsigned a, wa;
-                unsigned long long sall, sact, spop, spush, sx;
-                asm volatile(
-                    "s_mov_b64 %[sall], exec\n\t"
-                    "v_cmp_gt_i32 vcc, %[staged], %[c]\n\t"
-                    "v_add_u32 %[a], -1, %[cnt]\n\t"
-                    "s_and_b64 %[sact], vcc, exec\n\t"
-                    "v_and_b32 %[a], 7, %[a]\n\t"
-                    "v_add_u32 %[wa], 1, %[c]\n\t"
-                    "v_lshl_add_u32 %[a], %[a], 11, %[lb]\n\t"
-                    "v_and_b32 %[wa], %[cwm], %[wa]\n\t"
-                    "ds_read_b32 %[lv], %[a]\n\t"
-                    "ds_read_b32 %[lp], %[a] offset:16384\n\t"
-                    "ds_read_b32 %[lz], %[a] offset:32768\n\t"
-                    "v_lshl_add_u32 %[a], %[wa], 11, %[fwb]\n\t"
-                    "v_lshl_add_u32 %[wa], %[wa], 2, %[qwb]\n\t"
-                    "ds_read_b32 %[nh], %[a]\n\t"
-                    "ds_read_b32 %[nq], %[wa]\n\t"
-                    "v_sub_f32 %[qd], %[twoq], %[tv]\n\t"
-                    "v_sub_f32 %[qn], %[hq], %[tp]\n\t"
-                    "v_rcp_f32 %[qr], %[qd]\n\t"
-                    "v_and_b32 %[wa], 7, %[cnt]\n\t"
-                    "v_mul_f32 %[s], %[qn], %[qr]\n\t"
-                    "v_fma_f32 %[qe], -%[qd], %[s], %[qn]\n\t"
-                    "v_fmac_f32 %[s], %[qe], %[qr]\n\t"
-                    "v_lshl_add_u32 %[wa], %[wa], 11, %[lb]\n\t"
-                    "v_cmp_le_f32 vcc, %[s], %[tz]\n\t"
-                    "s_and_b64 %[spop], vcc, %[sact]\n\t"
-                    "s_andn2_b64 %[spush], %[sact], %[spop]\n\t"
-                    "s_waitcnt lgkmcnt(0)\n\t"
-                    "s_mov_b64 exec, %[spush]\n\t"
-                    "ds_write2st64_b32 %[wa], %[tv], %[tp] offset1:64\n\t"
-                    "ds_write_b32 %[wa], %[tz] offset:32768\n\t"
-                    "v_add_u32 %[cnt], 1, %[cnt]\n\t"
-                    "v_add_u32 %[c], 1, %[c]\n\t"
-                    "v_mov_b32 %[tv], %[twoq]\n\t"
-                    "v_mov_b32 %[tp], %[hq]\n\t"
-                    "v_mov_b32 %[tz], %[s]\n\t"
-                    "v_mov_b32 %[hq], %[nh]\n\t"
-                    "v_mov_b32 %[twoq], %[nq]\n\t"
-                    "s_mov_b64 exec, %[spop]\n\t"
-                    "v_add_u32 %[cnt], -1, %[cnt]\n\t"
-                    "v_mov_b32 %[tv], %[lv]\n\t"
-                    "v_mov_b32 %[tp], %[lp]\n\t"
-                    "v_mov_b32 %[tz], %[lz]\n\t"
-                    "s_mov_b64 exec, %[sact]\n\t"
-                    "v_sub_u32 %[a], %[cnt], %[base]\n\t"
-                    "v_cmp_lt_i32 %[sx], 0, %[cnt]\n\t"
-                    "v_and_b32 %[a], 7, %[a]\n\t"
-                    "v_cmp_eq_u32 vcc, 0, %[a]\n\t"
-                    "s_and_b64 %[sx], %[sx], vcc\n\t"
-                    "s_cselect_b32 %[flag], 1, 0\n\t"
-                    "s_mov_b64 exec, %[sall]"
-                    : [s] "=&v"(s), [tv] "+v"(tvx2), [tp] "+v"(tP), [tz] "+v"(tz), [cnt] "+v"(cnt), [c] "+v"(c), [hq] "+v"(hq), [twoq] "+v"(twoq),
-                      [flag] "=&s"(flag), [lv] "=&v"(lv), [lp] "=&v"(lp), [lz] "=&v"(lz), [nh] "=&v"(nh), [nq] "=&v"(nq), [qd] "=&v"(qd), [qn] "=&v"(qn), [qr] "=&v"(qr),
-                      [qe] "=&v"(qe), [a] "=&v"(a), [wa] "=&v"(wa), [sall] "=&s"(sall), [sact] "=&s"(sact), [spop] "=&s"(spop), [spush] "=&s"(spush),
-                      [sx] "=&s"(sx)
-                    : [staged] "s"(staged), [lb] "v"(lb), [fwb] "v"(fwb), [qwb] "s"(qwb), [base] "v"(base), [cwm] "n"(kCW - 1)
-                    : "vcc", "scc", "memory");
-            }
-#ifdef FDCM_LAB
-            cyc_pass += __builtin_amdgcn_s_memtime() - cp0;
-#endif
-        }
-    }
-#ifdef FDCM_LAB
-    if (lab && lane == 0) { lab[16] = n_pass; lab[17] = n_stage; lab[18] = n_flag; lab[19] = cyc_pass; lab[20] = cyc_stage; lab[21] = __builtin_amdgcn_s_memtime() - cyc0; }
-#endif
-    local_finish(ring, ent, tid, tvx2, tP, tz, cnt, base);
-    cnt_out = cnt; base_out = base;
-}
-#endif  // FDCM_LAB
+// (Round 5 built a local run with a column cursor per lane for lab builds -- FDCM_SWEEP_LOCAL=cursors: the longest wave makes 201
+// passes instead of 482 and the kernel is slower, 0.22 against 0.195 ms, because a pass with its own cursor is ~45 instructions
+// against 20; profiles/NOTES.md section 11.  It was removed in round 6 when the ranges became dynamic; git history has it.)
 
 // ---- Phase 2 lane layout: wave j works on the rows 8 j .. 8 j + 7 of the chunk, lane = 8 g + t with g the row inside
 // the wave and t = 0..7.  The 8 lanes of a row hold the row's state in copies and spend their width on 8 stack entries
@@ -923,7 +728,7 @@ __device__ __forceinline__ void fill_part(SweepLds& L, float* __restrict__ vol, 
 __global__ void __launch_bounds__(kNT) k_sweep_balanced(const ColDesc* __restrict__ desc, float* __restrict__ vol, int W, int H, int HW64, int part_w,
                                                         SweepBuf B) {
     // one LDS pool for the phases: the construction's rings (kept through the merge), the walk's lists, the fill's staging
-    constexpr size_t kPoolBytes = std::max({(size_t)(3 * kRing + kLabWin) * kNT * sizeof(float), (size_t)3 * 64 * kWinStride * 4, (size_t)3 * kRE * kNT * 4});
+    constexpr size_t kPoolBytes = std::max({(size_t)3 * kRing * kNT * sizeof(float), (size_t)3 * 64 * kWinStride * 4, (size_t)3 * kRE * kNT * 4});
     __shared__ SweepLds L;
     __shared__ float4 pool[kPoolBytes / sizeof(float4)];
     const long long t_start = wall_clock64();
@@ -1158,11 +963,6 @@ void launch_sweep_balanced(hipStream_t st, const void* desc, float* vol, int W, 
     if (env_heavy >= 0) B.steal_heavy_only = env_heavy;
     else if (env_steal >= 0) B.steal_heavy_only = 0;
     B.steal_cols = env_steal >= 0 ? 0 : kStealCols;  // (the forced threshold counts blocks only: small test images have blocks of one column)
-#ifdef FDCM_LAB
-    // FDCM_SWEEP_LOCAL=cursors (lab builds): the local run with a column cursor per lane, for comparisons
-    static const int env_cursors = [] { const char* e = getenv("FDCM_SWEEP_LOCAL"); return (e && std::strcmp(e, "cursors") == 0) ? 1 : 0; }();
-    B.lane_cursors = env_cursors;
-#endif
 #ifdef FDCM_LAB
     if (getenv("FDCM_SWEEP_LAB")) {  // per-wave phase times (100 MHz clock) and counters of this launch, on stderr
         static DevBuf labbuf;
