@@ -666,6 +666,23 @@ def test_randomised_cases(amd, env, cases, seed):
         assert taken == 0, out.stdout[-500:]
 
 
+@pytest.mark.parametrize("env", [{}, {"FDCM_SWEEP_STEAL": "1"}], ids=["default-cuts", "cuts-at-every-chance"])
+def test_dynamic_cuts_at_full_size(amd, env):
+    """The L2 sweep's waves cut a row's columns among themselves as they go (whoever runs dry takes over the far half of what
+    nobody has started): the cuts depend on timing, so every build of a scene is cut differently -- and must be the oracle's
+    volume bit for bit every time (tools/soak_volumes.py: config 2 scenes of seeds the other tests do not use, L2 and L2^2, each
+    built twice on one handle, and one config 3 scene)."""
+    import os
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_volumes.py"), "41", "3", "2", "1"], capture_output=True, text=True,
+                         timeout=900, env={**os.environ, **env})
+    assert out.returncode == 0 and "14 full-size builds identical" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+    assert int(re.search(r"(\d+) ranges taken over", out.stdout).group(1)) > 0, out.stdout[-300:]
+
+
 @pytest.mark.parametrize("env", [{}, {"FDCM_SWEEP_ORDER": "1"}], ids=["default", "launch-order-from-history"])
 def test_rebuilds_of_one_handle(amd, env):
     """A handle rebuilt over scenes of changing content and size (tools/rebuild_parity.py): every volume bit for bit.
