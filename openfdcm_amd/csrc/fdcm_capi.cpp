@@ -3,7 +3,10 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdlib>
+#include <condition_variable>
 #include <cstring>
+#include <deque>
+#include <functional>
 #include <mutex>
 #include <numeric>
 #include <thread>
@@ -536,14 +539,109 @@ int fdcm_penalize(int penalty, float tau, fdcm_match* matches, int64_t n, const 
     });
 }
 
-// sortMatches (matchstrategy.h:46-50): std::sort by score -- unstable, and which of two equal scores comes first is
-// whatever libstdc++'s introsort does, so it is that very call.  (Measured alternatives, profiles/NOTES.md section 12: a
-// frame of 27 000 matches always holds a few equal scores, so a radix sort cannot replace it; std::sort over
-// (score, position) pairs, a block-partition restatement of introsort and a parallel one all end in the same
-// permutation and none is faster than 1.4 - 2 ms.)
+// sortMatches (matchstrategy.h:46-50): std::sort by score -- unstable, and which of two equal scores comes first is whatever
+// libstdc++'s introsort does (a frame of 27 000 matches always holds a few equal scores, so nothing but that algorithm gives the
+// reference's list).  Its moves depend on the comparisons only, so (a) sorting (score, position) pairs and gathering the records
+// ends in the same permutation, and (b) so does running it on a few threads: introsort recurses on the right part of every
+// partition and loops on the left, the parts never exchange elements again, and the closing insertion sort never moves an
+// element across a partition boundary (everything left of it is <= everything right of it).  Here the first three partition
+// levels hand their right parts to a small persistent pool and every part then runs libstdc++'s own std::__introsort_loop +
+// std::__final_insertion_sort: 1.27 -> 0.49 ms for 27 025 records on the GPU box's host (tools/sim/sort_pool_bench.cpp;
+// tests/test_matchlist.py compares with std::sort on the reference's Match structs, ties, +-0 and +-inf included).  Lists below
+// 8192 records, lists with a NaN score (no strict weak order: the serial scan's behaviour is its own) and calls that find the
+// pool busy take the plain std::sort.
+namespace {
+#if defined(__GLIBCXX__)
+struct SortKey { float score; uint32_t pos; };
+struct SortKeyLess { bool operator()(const SortKey& a, const SortKey& b) const { return a.score < b.score; } };
+class SortPool {
+    std::mutex mu;
+    std::condition_variable cv_task, cv_done;
+    std::deque<std::function<void()>> q;
+    int pending = 0;
+    void loop() {
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            cv_task.wait(lk, [&] { return !q.empty(); });
+            auto f = std::move(q.front());
+            q.pop_front();
+            lk.unlock();
+            f();
+            lk.lock();
+            if (--pending == 0) cv_done.notify_all();
+        }
+    }
+public:
+    std::mutex in_use;  // one sort at a time
+    explicit SortPool(int helpers) {
+        for (int i = 0; i < helpers; ++i) std::thread([this] { loop(); }).detach();  // (they live as long as the process: the pool is never destroyed)
+    }
+    void submit(std::function<void()> f) {
+        { std::lock_guard<std::mutex> lk(mu); ++pending; q.push_back(std::move(f)); }
+        cv_task.notify_one();
+    }
+    void help_and_wait() {  // the caller's thread works the queue too, then waits for the helpers' last tasks
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            if (!q.empty()) {
+                auto f = std::move(q.front());
+                q.pop_front();
+                lk.unlock();
+                f();
+                lk.lock();
+                if (--pending == 0) cv_done.notify_all();
+                continue;
+            }
+            if (pending == 0) return;
+            cv_done.wait(lk, [&] { return pending == 0 || !q.empty(); });
+        }
+    }
+};
+SortPool* sort_pool() {
+    static SortPool* p = [] {
+        const unsigned hc = std::thread::hardware_concurrency();
+        return hc >= 4 ? new SortPool((int)std::min(7u, hc - 1)) : nullptr;
+    }();
+    return p;
+}
+void sort_part(SortKey* first, SortKey* last, long depth, int levels, SortPool* P) {
+    auto cmp = __gnu_cxx::__ops::__iter_comp_iter(SortKeyLess{});
+    while (levels > 0 && last - first > 2048 && depth > 0) {  // std::__introsort_loop's own steps, the right part to the pool
+        --depth; --levels;
+        SortKey* cut = std::__unguarded_partition_pivot(first, last, cmp);
+        P->submit([=] { sort_part(cut, last, depth, levels, P); });
+        last = cut;
+    }
+    std::__introsort_loop(first, last, depth, cmp);
+    std::__final_insertion_sort(first, last, cmp);
+}
+bool sort_matches_parallel(fdcm_match* matches, int64_t n) {
+    if (n < 8192 || n > (int64_t)UINT32_MAX) return false;
+    SortPool* P = sort_pool();
+    if (!P) return false;
+    std::unique_lock<std::mutex> use(P->in_use, std::try_to_lock);
+    if (!use.owns_lock()) return false;
+    std::vector<SortKey> key((size_t)n);
+    for (int64_t i = 0; i < n; ++i) {
+        if (matches[i].score != matches[i].score) return false;  // NaN
+        key[(size_t)i] = {matches[i].score, (uint32_t)i};
+    }
+    sort_part(key.data(), key.data() + n, (long)std::__lg(n) * 2, 3, P);
+    P->help_and_wait();
+    std::vector<fdcm_match> out((size_t)n);
+    for (int64_t i = 0; i < n; ++i) out[(size_t)i] = matches[key[(size_t)i].pos];
+    std::memcpy(matches, out.data(), (size_t)n * sizeof(fdcm_match));
+    return true;
+}
+#else
+bool sort_matches_parallel(fdcm_match*, int64_t) { return false; }
+#endif
+}  // namespace
+
 int fdcm_sort_matches(fdcm_match* matches, int64_t n) {
     return guarded([&] {
         require(n >= 0 && (n == 0 || matches), "bad matches");
+        if (sort_matches_parallel(matches, n)) return;
         std::sort(matches, matches + n, [](const fdcm_match& a, const fdcm_match& b) { return a.score < b.score; });
     });
 }

@@ -189,3 +189,40 @@ def test_copy_and_pickle():
     restructured = MatchList(make_records(4, seed=6))
     restructured.reverse()
     assert pickle.loads(pickle.dumps(restructured)) == restructured
+
+
+def test_parallel_sort_is_std_sort():
+    """fdcm_sort_matches above 8192 records runs libstdc++'s introsort on a few threads (csrc/fdcm_capi.cpp): the permutation
+    must be std::sort's on the reference's Match structs for every shape of input -- many ties, all equal, sorted, reversed,
+    saw-tooth -- and for several callers at once (one gets the pool, the others the plain std::sort)."""
+    import threading
+    from oracle import oracle as O
+    rng = np.random.default_rng(21)
+    shapes = {
+        "three values": lambda n: rng.integers(0, 3, n).astype(np.float32),
+        "all equal": lambda n: np.full(n, 2.5, np.float32),
+        "sorted": lambda n: np.arange(n, dtype=np.float32),
+        "reversed": lambda n: np.arange(n, 0, -1).astype(np.float32),
+        "saw-tooth": lambda n: (np.arange(n) % 97).astype(np.float32),
+        "random + ties": lambda n: np.round(rng.standard_normal(n) * 50).astype(np.float32),
+        "random": lambda n: rng.standard_normal(n).astype(np.float32),
+        "organ pipe": lambda n: np.minimum(np.arange(n), n - np.arange(n)).astype(np.float32),
+    }
+    for n in (8192, 8193, 20000, 27025, 131072):
+        for name, make in shapes.items():
+            rec = make_records(n, seed=n % 1000)
+            rec["score"] = make(n)
+            got = rec.copy()
+            _capi.check(_capi.lib().fdcm_sort_matches(got.ctypes.data, n))
+            assert got.tobytes() == O.sort_matches(rec).tobytes(), (n, name)
+    recs = [make_records(30000, seed=s) for s in range(6)]
+    for r in recs:
+        r["score"] = np.round(r["score"])          # ties
+    outs = [r.copy() for r in recs]
+    th = [threading.Thread(target=lambda o=o: _capi.check(_capi.lib().fdcm_sort_matches(o.ctypes.data, len(o)))) for o in outs]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for r, o in zip(recs, outs):
+        assert o.tobytes() == O.sort_matches(r).tobytes()
