@@ -60,6 +60,33 @@ def so_hash():
     return hashlib.sha256(open(p, "rb").read()).hexdigest()[:16]
 
 
+def device_code_hash(path):
+    """sha256[:16] of the library's .hip_fatbin section (the gfx950 code objects): what the GPU runs.  Host-only changes of the
+    library leave it alone, so a PMC summary stays valid for them."""
+    import struct
+    data = open(path, "rb").read()
+    if data[:4] != b"\x7fELF" or data[4] != 2:
+        return None
+    shoff, = struct.unpack_from("<Q", data, 0x28)
+    shentsize, shnum, shstrndx = struct.unpack_from("<HHH", data, 0x3A)
+    def sh(i):
+        name, typ, flags, addr, off, size = struct.unpack_from("<IIQQQQ", data, shoff + i * shentsize)
+        return name, off, size
+    _, stroff, strsize = sh(shstrndx)
+    for i in range(shnum):
+        name, off, size = sh(i)
+        end = data.index(b"\0", stroff + name)
+        if data[stroff + name:end] == b".hip_fatbin":
+            return hashlib.sha256(data[off:off + size]).hexdigest()[:16]
+    return None
+
+
+def pmc_is_of_this_library(doc):
+    """A PMC summary counts for the running library when it was measured on the same file, or on the same device code."""
+    so = os.path.join(ROOT, "openfdcm_amd", "libfdcm_hip.so")
+    return doc.get("so_sha256_16") == so_hash() or (doc.get("device_sha256_16") is not None and doc.get("device_sha256_16") == device_code_hash(so))
+
+
 def pmc_traffic(config):
     """HBM bytes per build (all build kernels) from a committed PMC summary (profiles/*pmc_traffic*<config>*.json:
     separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH doubled per MI355X_MICROARCH.md).  Counters cannot
@@ -70,7 +97,7 @@ def pmc_traffic(config):
     if not files:
         return None, "no PMC summary for this config under profiles/"
     doc = json.load(open(files[-1]))
-    if doc.get("so_sha256_16") != so_hash():
+    if not pmc_is_of_this_library(doc):
         return None, f"{os.path.basename(files[-1])} was measured on another build of libfdcm_hip.so"
     build = [v["hbm_bytes_per_launch"] * v.get("launches_per_frame", 1.0) for k, v in doc["kernels"].items()
              if any(t in k for t in ("k_seeds", "k_coldesc", "k_sweep", "k_pass2", "k_l1", "k_propagate", "k_integral"))]
@@ -86,7 +113,7 @@ def pmc_search_traffic(config):
     if not files:
         return None, None, "no PMC summary for this config under profiles/"
     doc = json.load(open(files[-1]))
-    if doc.get("so_sha256_16") != so_hash():
+    if not pmc_is_of_this_library(doc):
         return None, None, f"{os.path.basename(files[-1])} was measured on another build of libfdcm_hip.so"
     for k, v in doc["kernels"].items():
         if "k_search" in k:

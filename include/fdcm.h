@@ -276,6 +276,9 @@ int fdcm_filter_in_range(const float* lines, int64_t n_lines, const float center
 int fdcm_penalize(int penalty, float tau, fdcm_match* matches, int64_t n, const float* template_lengths,
                   int64_t n_templates);
 int fdcm_sort_matches(fdcm_match* matches, int64_t n);
+/* sortMatches(matches, maxNumCandidates) (matchstrategy.h:52-55): std::partial_sort -- the min(max_num_candidates, n) best in
+ * ascending score in front, the rest behind them in the order the algorithm leaves. */
+int fdcm_partial_sort_matches(fdcm_match* matches, int64_t n, int64_t max_num_candidates);
 
 /* ---- device tail: penalize + sort_matches + "the k best" on matches resident in HBM (the reference's callers do
  *      penalize(), sort_matches() and slice: README.md:71-72, python/src/matching.cpp:291-307).  matches_device:

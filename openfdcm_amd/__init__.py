@@ -423,11 +423,16 @@ def penalize(penalty, matches, templatelengths):
     return MatchList(rec)
 
 
-def sort_matches(matches):
-    """matching.cpp:302-307: ascending score (std::sort, unstable on ties)."""
+def sort_matches(matches, max_num_candidates=None):
+    """matching.cpp:302-307: ascending score (std::sort, unstable on ties; libstdc++'s order between equal scores).
+    max_num_candidates (extension: the C++ overload sortMatches(matches, maxNumCandidates), matchstrategy.h:52-55, which the
+    reference's Python module does not bind): std::partial_sort -- only that many best matches are put in order in front."""
     import ctypes as C
     rec = records_of(matches)
-    _capi.check(_capi.lib().fdcm_sort_matches(C.c_void_p(rec.ctypes.data), len(rec)))
+    if max_num_candidates is None:
+        _capi.check(_capi.lib().fdcm_sort_matches(C.c_void_p(rec.ctypes.data), len(rec)))
+    else:
+        _capi.check(_capi.lib().fdcm_partial_sort_matches(C.c_void_p(rec.ctypes.data), len(rec), int(max_num_candidates)))
     return MatchList(rec)
 
 

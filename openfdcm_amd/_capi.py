@@ -100,6 +100,7 @@ SYMBOLS = [
     ("fdcm_filter_in_range", C.c_int, [_fp, C.c_int64, _fp, C.c_float, C.c_float, _i64p, _i64p]),
     ("fdcm_penalize", C.c_int, [C.c_int, C.c_float, _vp, C.c_int64, _fp, C.c_int64]),
     ("fdcm_sort_matches", C.c_int, [_vp, C.c_int64]),
+    ("fdcm_partial_sort_matches", C.c_int, [_vp, C.c_int64, C.c_int64]),
     ("fdcm_lines_read", C.c_int, [C.c_char_p, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_int64)]),
     ("fdcm_lines_write", C.c_int, [C.c_char_p, _fp, C.c_int64]),
     ("fdcm_lines_free", None, [C.POINTER(C.c_float)]),

@@ -646,6 +646,16 @@ int fdcm_sort_matches(fdcm_match* matches, int64_t n) {
     });
 }
 
+// sortMatches(matches, maxNumCandidates), matchstrategy.h:52-55: std::partial_sort of the first min(k, n) places
+int fdcm_partial_sort_matches(fdcm_match* matches, int64_t n, int64_t max_num_candidates) {
+    return guarded([&] {
+        require(n >= 0 && (n == 0 || matches), "bad matches");
+        require(max_num_candidates >= 0, "max_num_candidates must be >= 0");
+        std::partial_sort(matches, matches + std::min<int64_t>(max_num_candidates, n), matches + n,
+                          [](const fdcm_match& a, const fdcm_match& b) { return a.score < b.score; });
+    });
+}
+
 // ------------------------------------------------------------------------------------------ line files (fdcm_lineio.cpp)
 int fdcm_lines_read(const char* path, float** lines, int64_t* n_lines) {
     return guarded([&] {

@@ -1038,6 +1038,10 @@ float fdcmo_atanf(float x) { return std::atan(x); }
 void fdcmo_sort_matches(Match* m, long n) {
     std::sort(m, m + n, [](const Match& a, const Match& b) { return a.score < b.score; });
 }
+// sortMatches(matches, maxNumCandidates), matchstrategy.h:52-55
+void fdcmo_partial_sort_matches(Match* m, long n, long k) {
+    std::partial_sort(m, m + std::min(k, n), m + n, [](const Match& a, const Match& b) { return a.score < b.score; });
+}
 // penalize<DefaultPenalty> (defaultpenalty.cpp:33-45) / penalize<ExponentialPenalty> (exponentialpenalty.cpp:33-48);
 // returns -1 where templatelengths.at() throws.
 int fdcmo_penalize(int exponential, float tau, Match* m, long n, const float* lengths, long n_lengths) {

@@ -87,6 +87,7 @@ def lib():
         _lib.fdcmo_atanf.restype = C.c_float
         _lib.fdcmo_atanf.argtypes = [C.c_float]
         _lib.fdcmo_sort_matches.argtypes = [vp, C.c_long]
+        _lib.fdcmo_partial_sort_matches.argtypes = [vp, C.c_long, C.c_long]
         _lib.fdcmo_penalize.restype = C.c_int
         _lib.fdcmo_penalize.argtypes = [C.c_int, C.c_float, vp, C.c_long, fp, C.c_long]
     return _lib
@@ -394,6 +395,13 @@ def sort_matches(records):
     """sortMatches (matchstrategy.h:46-50) on a copy of the MATCH_DTYPE records."""
     rec = np.array(records, dtype=MATCH_DTYPE, copy=True, order="C")
     lib().fdcmo_sort_matches(rec.ctypes.data, len(rec))
+    return rec
+
+
+def partial_sort_matches(records, k):
+    """sortMatches(matches, maxNumCandidates) (matchstrategy.h:52-55) on a copy of the records."""
+    rec = np.array(records, dtype=MATCH_DTYPE, copy=True, order="C")
+    lib().fdcmo_partial_sort_matches(rec.ctypes.data, len(rec), int(k))
     return rec
 
 

@@ -226,3 +226,20 @@ def test_parallel_sort_is_std_sort():
         t.join()
     for r, o in zip(recs, outs):
         assert o.tobytes() == O.sort_matches(r).tobytes()
+
+
+def test_partial_sort_is_the_reference_overload():
+    """sort_matches(matches, max_num_candidates) = sortMatches(matches, maxNumCandidates) (matchstrategy.h:52-55): std::partial_sort,
+    the whole array compared with the oracle's call (the tail's order is the algorithm's too)."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(5)
+    for n in (0, 1, 10, 1000, 20000):
+        rec = make_records(n, seed=n + 3)
+        rec["score"] = np.round(rng.standard_normal(n) * 20).astype(np.float32)   # ties
+        for k in (0, 1, 7, n // 2, n, n + 5):
+            got = records_of(api.sort_matches(MatchList(rec.copy()), max_num_candidates=k))
+            assert got.tobytes() == O.partial_sort_matches(rec, k).tobytes(), (n, k)
+            kk = min(k, n)
+            assert np.all(np.diff(got["score"][:kk]) >= 0) and (kk == n or kk == 0 or got["score"][kk - 1] <= got["score"][kk:].min())
+    with pytest.raises(_capi.FdcmError):
+        api.sort_matches(MatchList(make_records(5)), max_num_candidates=-1)

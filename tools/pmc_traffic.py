@@ -23,6 +23,28 @@ import json
 import sys
 
 
+def device_code_hash(path):
+    """sha256[:16] of the library's .hip_fatbin section (the gfx950 code objects); the same function as in bench.py."""
+    import hashlib
+    import struct
+    data = open(path, "rb").read()
+    if data[:4] != b"\x7fELF" or data[4] != 2:
+        return None
+    shoff, = struct.unpack_from("<Q", data, 0x28)
+    shentsize, shnum, shstrndx = struct.unpack_from("<HHH", data, 0x3A)
+
+    def sh(i):
+        name, typ, flags, addr, off, size = struct.unpack_from("<IIQQQQ", data, shoff + i * shentsize)
+        return name, off, size
+    _, stroff, strsize = sh(shstrndx)
+    for i in range(shnum):
+        name, off, size = sh(i)
+        end = data.index(b"\0", stroff + name)
+        if data[stroff + name:end] == b".hip_fatbin":
+            return hashlib.sha256(data[off:off + size]).hexdigest()[:16]
+    return None
+
+
 def per_kernel(d, counter):
     f = glob.glob(f"{d}/**/*counter_collection.csv", recursive=True)[0]
     agg = collections.defaultdict(list)
@@ -52,6 +74,7 @@ def main():
     json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- " + (sys.argv[4] if len(sys.argv) > 4 else
                          "python3 bench.py --frames 1 --steps 5 --warmup 2 --cpu-sample 0 --single-frames 0"),
                "so_sha256_16": hashlib.sha256(open(so, "rb").read()).hexdigest()[:16],
+               "device_sha256_16": device_code_hash(so),  # of the .hip_fatbin section: host-only changes of the library keep the summary valid
                "kernels": out}, open(sys.argv[3], "w"), indent=1)
     print(json.dumps(out, indent=1))
 
