@@ -159,9 +159,9 @@ class FrameShards:
         mine = [(tag,) + self.digest(rec, below_template) for tag, rec in frames]
         if not dist.is_initialized():
             return [mine]
-        out = [None] * self.world if self.rank == dst else None
-        dist.gather_object(mine, out, dst=dst, group=self.group)
-        return out
+        out = [None] * self.world
+        dist.all_gather_object(out, mine, group=self.group)  # (all_gather: the object collective every backend has had for longest)
+        return out if self.rank == dst else None
 
 
 class FrameGatherer:
