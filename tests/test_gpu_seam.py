@@ -246,3 +246,17 @@ def test_type_erasure_shells_are_usable(built_pair):
     b = openfdcm.search(openfdcm.MatchStrategy(openfdcm.DefaultMatch()), openfdcm.SearchStrategy(conc),
                         openfdcm.OptimizeStrategy(openfdcm.BatchOptimize(4)), erased, tmpls, scene)
     assert len(a) == len(b) and all(x.score == y.score for x, y in zip(a, b))
+
+
+def test_pin_against_reference_script_runs_with_a_stand_in():
+    """tools/pin_against_reference.py compares the real reference (where its wheel is installed) with the oracle and the HIP path;
+    here openfdcm_amd plays the reference's part so that every line of the script runs: config 1 from the shipped assets and
+    config 2 (three distances, two optimisers, the penalised and sorted list)."""
+    import os
+    import subprocess
+    import sys
+    from helpers import ROOT
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pin_against_reference.py"), "--stand-in", "--templates", "60"],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "reference pin: all identical" in out.stdout and "DIFF" not in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
+    assert out.stdout.count("ok   ") >= 20
