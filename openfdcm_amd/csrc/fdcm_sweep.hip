@@ -81,8 +81,9 @@ struct Ring {
 // stretch when it gets there (an atomic OR on a bit map in LDS), and stops where somebody else's range begins.
 static constexpr int kMaxR = 16;     // ranges per row at most (initial + taken over)
 static constexpr int kMaxBlk = 128;  // claim blocks per slice at most (two 64-bit words)
-static constexpr int kStealMin = 2;   // .. and kStealCols columns
-static constexpr int kStealCols = 16;  // blocks an unclaimed stretch must have for a wave out of columns to begin a new range in its middle (FDCM_SWEEP_STEAL)
+static constexpr int kStealMin = 1;   // blocks an unclaimed stretch must have for a wave out of columns to begin a new range in its middle (FDCM_SWEEP_STEAL)
+                                      // (mean of config 2's four scenes: 1 block 0.196 ms, 2 blocks 0.198 -- with an occasional 0.267 on seed 4 --, 3: 0.207, 6: 0.225)
+static constexpr int kStealCols = 8;  // .. and columns  // blocks an unclaimed stretch must have for a wave out of columns to begin a new range in its middle (FDCM_SWEEP_STEAL)
 struct SweepLds {
     unsigned long long smask[64];    // the slice's seeded columns, 64 per word (W <= 4096)
     unsigned long long claim[2];     // blocks of columns that have an owner
